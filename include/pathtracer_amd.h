@@ -1,0 +1,183 @@
+/*
+ * pathtracer_amd.h -- C ABI of the MI355X-native path-tracing integrator.
+ *
+ * The reference (kbau121/PathTracer) has no FFI layer; the boundary this
+ * library stands behind is `class Renderer` (src/renderer.h:12-39) fed by the
+ * flat arrays of `class Scene` (src/scene.h:53-62) and the axes of `class
+ * Camera` (src/camera.h:12-19).  Every entry point below names the reference
+ * interface it replaces.  All functions return PT_OK (0) or a negative error
+ * code and never throw; pt_last_error() describes the most recent failure on
+ * the calling thread.  A renderer is driven by one host thread at a time.
+ *
+ * Image convention: pixel index = y * width + x with row 0 the BOTTOM row, as
+ * gl_FragCoord numbers them (pathtracer.frag.glsl:310,866).
+ */
+#ifndef PATHTRACER_AMD_H
+#define PATHTRACER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_ERR_INVALID -1   /* bad argument                         */
+#define PT_ERR_IO -2        /* file could not be read               */
+#define PT_ERR_DEVICE -3    /* HIP call failed / no usable GPU      */
+#define PT_ERR_STATE -4     /* call not valid in the current state  */
+
+/* Hit codes written by pt_read_hit_ids: a triangle index >= 0 (position in
+ * Scene::m_indices), PT_HIT_MISS, or PT_HIT_LIGHT(k) for light k. */
+#define PT_HIT_MISS (-1)
+#define PT_HIT_LIGHT(k) (-(2 + (k)))
+
+typedef struct pt_scene pt_scene;
+typedef struct pt_camera pt_camera;
+typedef struct pt_renderer pt_renderer;
+
+/* The six device-bound arrays of Scene exactly as the reference lays them out
+ * and uploads them (scene.h:53-62, renderer.cpp:32-83), so a host Scene can be
+ * handed over without conversion.  Pointers are host memory, read during the
+ * call only and never retained. */
+typedef struct {
+    const float *vertices;        /* n_vertices x 3                       m_vertices    */
+    uint32_t n_vertices;
+    const float *indices;         /* n_triangles x 4 floats (i0,i1,i2,w)  m_indices     */
+    uint32_t n_triangles;
+    const float *vertex_data;     /* 3*n_triangles x 6 (normal, uv0)      m_vertexData  */
+    const float *lights;          /* n_lights x 20 (radiance4, mat4)      m_lights      */
+    uint32_t n_lights;            /*                                      m_lightCount[0] */
+    const float *materials;       /* n_materials x 8                      m_materials   */
+    uint32_t n_materials;
+    const uint32_t *material_map; /* n_triangles                          m_materialMap */
+} pt_scene_desc;
+
+/* Values the reference hard-codes, as parameters with the reference's values
+ * as defaults (pt_config_default). */
+typedef struct {
+    uint32_t width, height;        /* Camera::m_resolution, main.cpp:126: 1280 x 720   */
+    uint32_t max_depth;            /* pathtracer.frag.glsl:874: 10                      */
+    float fov_y_degrees;           /* pathtracer.frag.glsl:306: 19.5                    */
+    int32_t device;                /* HIP device ordinal; -1 = current device           */
+    uint32_t use_bvh;              /* 1 = SAH BVH traversal; 0 = linear scan in the
+                                      reference's triangle order (frag:391-416)         */
+    uint32_t iterations_per_batch; /* samples per pixel in flight at once; 0 = auto     */
+    uint32_t profile;              /* 1 = time every kernel with HIP events (slower)    */
+} pt_config;
+
+typedef struct {
+    uint64_t iterations;      /* samples per pixel rendered by THIS renderer since reset */
+    uint64_t paths;           /* pixel-samples traced                                    */
+    uint64_t segments;        /* rays cast (extend work items)                           */
+    uint64_t nan_samples;     /* non-finite samples replaced by 0                        */
+    uint64_t nodes_visited;   /* BVH inner nodes fetched   (profile builds only)         */
+    uint64_t tris_tested;     /* triangle tests            (profile builds only)         */
+    uint32_t n_triangles, n_nodes, bvh_depth, stack_entries;
+    double bvh_build_ms, upload_ms;
+    /* Sums of HIP-event durations per kernel and launch counts (profile = 1). */
+    double ms_raygen, ms_extend, ms_shade, ms_accumulate;
+    uint64_t launches_raygen, launches_extend, launches_shade, launches_accumulate;
+    double sah_cost;
+} pt_stats;
+
+const char *pt_last_error(void);
+const char *pt_version(void);
+/* Number of visible HIP devices; negative error code when the runtime fails. */
+int pt_device_count(void);
+
+/* ------------------------------------------------------------------ Scene
+ * Replaces Scene::Scene(objFilename, mtlRoot), Scene::Scene() and the public
+ * vectors (scene.h:64-218). */
+int pt_scene_load_obj(const char *obj_path, const char *mtl_root, pt_scene **out);
+int pt_scene_create_default(pt_scene **out);                      /* scene.h:64-76 */
+int pt_scene_from_desc(const pt_scene_desc *desc, pt_scene **out);
+void pt_scene_destroy(pt_scene *scene);
+/* Fills desc with pointers into the scene's own arrays (valid until the scene
+ * is modified or destroyed). */
+int pt_scene_get_desc(const pt_scene *scene, pt_scene_desc *desc);
+/* Scene::Light(radiance, position, rotation, scale) (scene.h:32-34): writes the
+ * 20 floats of one light record. */
+int pt_light_make(const float radiance[3], const float position[3], const float rotation[3],
+                  const float scale[3], float out_light[20]);
+/* Replaces m_lights / m_lightCount (main.cpp:122-123 assigns them directly). */
+int pt_scene_set_lights(pt_scene *scene, const float *lights, uint32_t n_lights);
+/* The light main.cpp:122 installs. */
+int pt_scene_set_default_light(pt_scene *scene);
+/* Deterministic stress scene: shapes after the first room_triangles triangles
+ * instanced on an n^3 lattice (see Scene::instanceLattice). */
+int pt_scene_instance_lattice(const pt_scene *base, uint32_t room_triangles, uint32_t n, pt_scene **out);
+
+/* ----------------------------------------------------------------- Camera
+ * Replaces class Camera (camera.h:22-33, camera.cpp). */
+int pt_camera_create(const float eye[3], const float focus[3], uint32_t width, uint32_t height,
+                     pt_camera **out);
+void pt_camera_destroy(pt_camera *cam);
+int pt_camera_look_at(pt_camera *cam, const float focus[3], const float *eye_or_null); /* camera.cpp:12-22 */
+int pt_camera_move(pt_camera *cam, const float offset[3]);                             /* camera.cpp:25-29 */
+int pt_camera_pan(pt_camera *cam, float dx, float dy);                                 /* camera.cpp:32-35 */
+int pt_camera_orbit(pt_camera *cam, float dx, float dy);                               /* camera.cpp:38-76 */
+int pt_camera_zoom(pt_camera *cam, float scale);                                       /* camera.cpp:79-86 */
+int pt_camera_update(pt_camera *cam);                                                  /* camera.cpp:89-95 */
+/* out = eye, focus, forward, up, right (15 floats); res = width, height. */
+int pt_camera_get(const pt_camera *cam, float out[15], uint32_t res[2]);
+
+/* --------------------------------------------------------------- Renderer */
+void pt_config_default(pt_config *cfg);
+/* Renderer::Renderer (renderer.cpp:11-112): copies the scene to the device
+ * (building the BVH and the SoA records on the way).  The scene is immutable
+ * afterwards; nothing in desc is retained. */
+int pt_create(const pt_scene_desc *scene, const pt_config *cfg, pt_renderer **out);
+void pt_destroy(pt_renderer *r);                                   /* renderer.cpp:114-122 */
+/* Renderer::updateCamera (renderer.cpp:189-202) with the axes Camera::update
+ * produced; resets the accumulation. */
+int pt_set_camera(pt_renderer *r, const float eye[3], const float forward[3], const float up[3],
+                  const float right[3]);
+int pt_resize(pt_renderer *r, uint32_t width, uint32_t height);    /* renderer.cpp:160-187 */
+int pt_reset(pt_renderer *r);                                      /* renderer.cpp:152-158 */
+/* n calls of Renderer::draw (renderer.cpp:124-150): n more samples per pixel.
+ * Sample k uses iterationCount = first + k * stride of the partition set by
+ * pt_set_partition (default first 0, stride 1).  Asynchronous. */
+int pt_render(pt_renderer *r, uint32_t n_iterations);
+/* Sample-space partition for one-process-per-GPU runs: this renderer renders
+ * iterations rank, rank + world, rank + 2*world, ...  Resets the accumulation. */
+int pt_set_partition(pt_renderer *r, uint32_t rank, uint32_t world);
+int pt_synchronize(pt_renderer *r);
+
+/* Readbacks (the reference shows the image in a window; none of these has a
+ * counterpart there).  All synchronise first. */
+/* Sum of samples: width*height*4 floats, rgb = radiance sum, a = sample count. */
+int pt_read_sum(pt_renderer *r, float *rgba_host);
+/* Mean radiance (sum / count): the float equivalent of the accumulation texture. */
+int pt_read_radiance(pt_renderer *r, float *rgba_host);
+/* post.frag:11-15 (Reinhard then gamma 1/2.2) on the mean, as 8-bit RGB,
+ * row 0 = TOP row (image-file order). */
+int pt_read_tonemapped(pt_renderer *r, uint8_t *rgb_host);
+/* Primary-ray hit codes of iteration `iteration` for every pixel. t_host and
+ * dirs_host (3 floats per pixel) may be NULL. Does not touch the accumulation. */
+int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids_host, float *t_host, float *dirs_host);
+/* Closest hit of n caller-supplied rays (origins/dirs: 3 floats each, host
+ * memory) through the same extend kernel the renderer uses. */
+int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float *dirs, float *t_host,
+                  int32_t *ids_host);
+/* One sampleSurface evaluation per record on the GPU (pathtracer.frag.glsl:
+ * 841-858) for testing the BSDF stage in isolation.  Per record: material 8
+ * floats, normal 3, wo 3, xi 2, seed 2 (uint32).  Outputs: wi 3, pdf 1, f 3,
+ * flags 1 (bit 0 = the lobe returned without a direction), seed_out 2. */
+int pt_sample_surface(pt_renderer *r, uint64_t n, const float *materials, const float *normals,
+                      const float *wo, const float *xi, const uint32_t *seeds, float *wi_out, float *pdf_out,
+                      float *f_out, uint32_t *flags_out, uint32_t *seeds_out);
+
+/* Device pointer of the sum buffer (width*height*4 floats) so that a caller
+ * can reduce it across GPUs without a host round trip; valid until
+ * pt_resize / pt_destroy. */
+int pt_sum_device_ptr(pt_renderer *r, void **dev_ptr);
+/* Adds to the per-renderer sample counter after an external reduction wrote
+ * other ranks' sums into the buffer (so that pt_read_radiance divides by the
+ * global count). */
+int pt_get_stats(pt_renderer *r, pt_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,37 @@
+// Records shared by the host uploader and the gfx950 kernels.
+#pragma once
+#include <cstdint>
+
+namespace pt {
+
+// One light as the kernels read it (the reference keeps radiance + transform
+// and inverts the transform per ray, pathtracer.frag.glsl:92-103; here the
+// inverse is taken once on the host).
+struct DeviceLight {
+    float radiance[4];
+    float inv[16];     // inverse transform, column-major
+    float normal[4];   // transform * (0,0,1,0)  (frag:457)
+};
+
+// Per original triangle, what shading needs (frag:434-453): the three
+// positions for the barycentrics, the three corner normals and the material.
+//   s0 = (v0.xyz, n1.x)  s1 = (v1.xyz, n1.y)  s2 = (v2.xyz, n1.z)
+//   s3 = (n2.xyz, material index bits)        s4 = (n3.xyz, 0)
+struct ShadeTriangle {
+    float s[20];
+};
+static_assert(sizeof(ShadeTriangle) == 80, "ShadeTriangle is five 16-byte lanes");
+
+struct DeviceCamera {
+    float eye[3];
+    float tan_half_fov;
+    float forward[3];
+    float aspect;
+    float up[3];
+    float width_f;
+    float right[3];
+    float height_f;
+    uint32_t width, height;
+};
+
+}  // namespace pt

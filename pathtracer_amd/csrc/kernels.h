@@ -1,0 +1,70 @@
+// Launch wrappers of the gfx950 wavefront-integrator kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_types.h"
+
+namespace pt {
+
+// Everything the kernels read about the scene; all pointers are device memory.
+struct SceneView {
+    const float4 *nodes;       // 4 lanes per BvhNode
+    const float4 *triangles;   // 4 lanes per BvhTriangle, leaf order (or scan order)
+    const float4 *shade;       // 5 lanes per ShadeTriangle, original order
+    const float4 *materials;   // 2 lanes per material
+    const DeviceLight *lights;
+    uint32_t n_triangles;
+    uint32_t n_materials;
+    uint32_t n_lights;
+    float scene_radius;        // largest |coordinate| of the mesh bounds
+};
+
+// One path queue: three 16-byte lanes per path.
+//   p0 = (origin.xyz, dir.x)  p1 = (dir.y, dir.z, seed.x, seed.y)  p2 = (throughput.rgb, sample slot)
+struct PathQueue {
+    float4 *p0;
+    float4 *p1;
+    float4 *p2;
+};
+
+struct TraversalCounters {
+    unsigned long long *nodes_visited;  // may be null
+    unsigned long long *tris_tested;
+};
+
+// Grid used by every kernel: persistent-style, grid-stride over the live count.
+struct LaunchShape {
+    uint32_t blocks;
+};
+
+void launch_raygen(hipStream_t s, LaunchShape g, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
+                   uint32_t n_iterations, PathQueue out, uint32_t *count_out);
+
+// stack_entries selects the traversal-stack instantiation (16, 32 or 64).
+void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
+                   const uint32_t *count, PathQueue q, float2 *hits, TraversalCounters tc);
+
+void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t bounce, uint32_t max_depth,
+                  const uint32_t *count_in, PathQueue in, const float2 *hits, PathQueue out, uint32_t *count_out,
+                  float4 *samples, unsigned long long *nan_counter);
+
+void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
+                       uint32_t n_iterations, const uint32_t *counts, uint32_t n_counts,
+                       unsigned long long *segments_total);
+
+// hits -> int32 hit codes / t / directions in pixel order for one iteration.
+void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *hits, int32_t *ids,
+                           float *t, float *dirs);
+
+void launch_pack_rays(hipStream_t s, LaunchShape g, uint32_t n, const float *origins, const float *dirs, PathQueue q,
+                      uint32_t *count_out);
+
+void launch_tonemap(hipStream_t s, LaunchShape g, const float4 *sum, uint8_t *rgb, uint32_t width, uint32_t height);
+
+void launch_sample_surface(hipStream_t s, LaunchShape g, uint32_t n, const float *materials, const float *normals,
+                           const float *wo, const float *xi, const uint32_t *seeds, float *wi_out, float *pdf_out,
+                           float *f_out, uint32_t *flags_out, uint32_t *seeds_out);
+
+}  // namespace pt

@@ -1,0 +1,840 @@
+// Wavefront path-tracing integrator for gfx950 (MI355X): raygen, extend
+// (BVH traversal with an LDS-resident stack, or a linear scan), shade (BSDF
+// sampling + wave64 ballot compaction) and accumulate.
+//
+// Arithmetic contract.  This file is compiled with -ffp-contract=off: every
+// '*', '+', '-', '/' below is one IEEE binary32 operation, and a fused
+// multiply-add happens only where fmaf() is spelled out (the conservative box
+// test).  The RNG, the camera ray, the triangle test and the light test follow
+// the evaluation trees of the reference shader as Mesa llvmpipe runs it
+// (pathtracer.frag.glsl:297-320, 363-431):
+//     dot(a,b)     = a.x*b.x + (a.y*b.y + a.z*b.z)
+//     normalize(v) = v * (1.0f / sqrtf(dot(v,v)))
+// so the primary hit buffer can be compared bit for bit.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace pt {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr float kPi = 3.14159265358979323f;     // frag:3
+constexpr float kInvPi = 0.31830988618379067f;  // frag:4
+
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ float dotm(f3 a, f3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ f3 crossm(f3 a, f3 b)
+{
+    return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ f3 normalizem(f3 v)
+{
+    float r = 1.0f / sqrtf(dotm(v, v));
+    return v * r;
+}
+
+// frag:297-304: all uint32 wrap-around; float(n) * 2^-32.
+__device__ __forceinline__ float rng_next(uint32_t &sx, uint32_t &sy)
+{
+    sx += 1u;
+    sy += 1u;
+    uint32_t qx = 1103515245u * ((sx >> 1) ^ sy);
+    uint32_t qy = 1103515245u * ((sy >> 1) ^ sx);
+    uint32_t n = 1103515245u * (qx ^ (qy >> 3));
+    return static_cast<float>(n) * 2.3283064365386963e-10f;
+}
+
+// ---------------------------------------------------------------- raygen
+
+// frag:866 + frag:306-320.  Path slot i = k * (W*H) + pixel, pixel = y*W + x.
+__global__ void __launch_bounds__(kBlock) k_raygen(DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
+                                                    uint32_t n_iterations, PathQueue out, uint32_t *count_out)
+{
+    const uint32_t n_pixels = cam.width * cam.height;
+    const uint32_t total = n_pixels * n_iterations;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = total;
+    const f3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
+    const f3 fwd = mk(cam.forward[0], cam.forward[1], cam.forward[2]);
+    const f3 up = mk(cam.up[0], cam.up[1], cam.up[2]);
+    const f3 right = mk(cam.right[0], cam.right[1], cam.right[2]);
+    const f3 ref = eye + fwd;
+    const f3 V = up * cam.tan_half_fov;
+    const f3 H = (right * cam.tan_half_fov) * cam.aspect;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+        const uint32_t k = i / n_pixels;
+        const uint32_t pixel = i - k * n_pixels;
+        const uint32_t y = pixel / cam.width;
+        const uint32_t x = pixel - y * cam.width;
+        const uint32_t iteration = it_first + k * it_stride;
+        uint32_t sx = (iteration + 1u) * x;
+        uint32_t sy = (iteration + 2u) * y;
+        const float jx = rng_next(sx, sy);
+        const float jy = rng_next(sx, sy);
+        float scx = ((static_cast<float>(x) + 0.5f) + jx) / cam.width_f;
+        float scy = ((static_cast<float>(y) + 0.5f) + jy) / cam.height_f;
+        scx = scx * 2.f - 1.f;
+        scy = scy * 2.f - 1.f;
+        const f3 p = (ref + H * scx) + V * scy;
+        const f3 d = normalizem(p - eye);
+        out.p0[i] = make_float4(eye.x, eye.y, eye.z, d.x);
+        out.p1[i] = make_float4(d.y, d.z, __uint_as_float(sx), __uint_as_float(sy));
+        out.p2[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(i));
+    }
+}
+
+// ---------------------------------------------------------------- extend
+
+struct Hit {
+    float t;
+    int id;  // original triangle index, -1 none
+};
+
+// frag:393-415 with n and dot(n,v0) hoisted (same operations, same bits).
+// Among equal t the larger original index wins, which is what visiting the
+// triangles in ascending index order with "reject only if st > t" produces.
+__device__ __forceinline__ void test_triangle(const float4 *__restrict__ tp, f3 o, f3 d, Hit &h)
+{
+    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+    const f3 v0 = mk(t0.x, t0.y, t0.z), v1 = mk(t1.x, t1.y, t1.z), v2 = mk(t2.x, t2.y, t2.z);
+    const f3 n = mk(t1.w, t2.w, t3.x);
+    const float st = (t0.w - dotm(n, o)) / dotm(n, d);
+    if (st < 0.f || st > h.t) return;
+    const f3 Q = mk(o.x + st * d.x, o.y + st * d.y, o.z + st * d.z);
+    if (dotm(crossm(v1 - v0, Q - v0), n) < 0.f) return;
+    if (dotm(crossm(v2 - v1, Q - v1), n) < 0.f) return;
+    if (dotm(crossm(v0 - v2, Q - v2), n) < 0.f) return;
+    const int orig = __float_as_int(t3.y);
+    if (st == h.t && orig < h.id) return;
+    h.t = st;
+    h.id = orig;
+}
+
+// frag:363-382, :418-430.  Rows evaluated ((m0*x + m1*y) + m2*z) + m3*w.
+__device__ __forceinline__ void test_lights(const SceneView &sc, f3 o, f3 d, float &t, int &code)
+{
+    for (uint32_t l = 0; l < sc.n_lights; ++l) {
+        const float *m = sc.lights[l].inv;
+        const float lox = ((m[0] * o.x + m[4] * o.y) + m[8] * o.z) + m[12] * 1.f;
+        const float loy = ((m[1] * o.x + m[5] * o.y) + m[9] * o.z) + m[13] * 1.f;
+        const float loz = ((m[2] * o.x + m[6] * o.y) + m[10] * o.z) + m[14] * 1.f;
+        const float ldx = ((m[0] * d.x + m[4] * d.y) + m[8] * d.z) + m[12] * 0.f;
+        const float ldy = ((m[1] * d.x + m[5] * d.y) + m[9] * d.z) + m[13] * 0.f;
+        const float ldz = ((m[2] * d.x + m[6] * d.y) + m[10] * d.z) + m[14] * 0.f;
+        const float dt = -ldz;
+        if (dt < 0.f) continue;
+        const float tl = loz / dt;
+        if (tl < 0.f) continue;
+        const float px = lox + ldx * tl, py = loy + ldy * tl;
+        if (!(fabsf(px) <= 0.5f && fabsf(py) <= 0.5f)) continue;
+        // A later light competes against t = 0 once one has been hit (frag:427).
+        const float limit = (code <= -2) ? 0.f : t;
+        if (tl < 0.f || tl > limit) continue;
+        t = tl;
+        code = -(2 + static_cast<int>(l));
+    }
+}
+
+// Linear scan in the reference's triangle order (frag:391-416).
+__global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, const uint32_t *__restrict__ count, PathQueue q,
+                                                         float2 *__restrict__ hits)
+{
+    const uint32_t n = *count;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float4 a = q.p0[i], b = q.p1[i];
+        const f3 o = mk(a.x, a.y, a.z), d = mk(a.w, b.x, b.y);
+        Hit h{__builtin_inff(), -1};
+        for (uint32_t t = 0; t < sc.n_triangles; ++t) test_triangle(sc.triangles + 4 * static_cast<size_t>(t), o, d, h);
+        float t = h.t;
+        int code = h.id;
+        test_lights(sc, o, d, t, code);
+        hits[i] = make_float2(t, __int_as_float(code));
+    }
+}
+
+// BVH traversal.  Each lane keeps its stack of deferred children in LDS,
+// laid out [entry][lane] so that a push/pop of all lanes touches consecutive
+// banks.  The stack can never hold more than one entry per inner level of the
+// tree, and the host instantiates STACK >= tree depth.
+//
+// Box test: the reference accepts hit points that lie a few ulp outside the
+// exact triangle, so a box may only be culled when the ray misses it by a
+// clear margin: every slab is widened by P = 2^-17 * max(|origin|, scene
+// radius) (64 ulp of the largest coordinate involved), and a box is skipped
+// only if its padded entry distance exceeds the best t so far, never on
+// equality, so ties in other subtrees are still visited.
+template <int STACK, bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_extend_bvh(SceneView sc, const uint32_t *__restrict__ count, PathQueue q,
+                                                        float2 *__restrict__ hits, TraversalCounters tc)
+{
+    __shared__ int stack[STACK * kBlock];
+    const uint32_t n = *count;
+    const uint32_t tid = threadIdx.x;
+    unsigned long long my_nodes = 0, my_tris = 0;
+    for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
+        const float4 a = q.p0[i], b = q.p1[i];
+        const f3 o = mk(a.x, a.y, a.z), d = mk(a.w, b.x, b.y);
+
+        // Reciprocal direction with zero components replaced by +-1e-30 so
+        // that no product below is inf * 0.
+        const float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+        const float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+        const float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        const float pad = 7.62939453125e-6f * fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), sc.scene_radius));
+        const float mx = pad * fabsf(ix), my = pad * fabsf(iy), mz = pad * fabsf(iz);
+        const float cnx = -(o.x * ix) - mx, cny = -(o.y * iy) - my, cnz = -(o.z * iz) - mz;  // entry planes
+        const float cfx = -(o.x * ix) + mx, cfy = -(o.y * iy) + my, cfz = -(o.z * iz) + mz;  // exit planes
+        const bool negx = ix < 0.f, negy = iy < 0.f, negz = iz < 0.f;
+
+        Hit h{__builtin_inff(), -1};
+        int node = 0;
+        int sp = 0;
+        for (;;) {
+            if (node >= 0) {
+                const float4 *np = sc.nodes + 4 * static_cast<size_t>(node);
+                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                if (COUNT) ++my_nodes;
+                // child 0: lo (n0.x n0.y n0.z) hi (n0.w n1.x n1.y); child 1: lo (n1.z n1.w n2.x) hi (n2.y n2.z n2.w)
+                const float e0x = negx ? n0.w : n0.x, x0x = negx ? n0.x : n0.w;
+                const float e0y = negy ? n1.x : n0.y, x0y = negy ? n0.y : n1.x;
+                const float e0z = negz ? n1.y : n0.z, x0z = negz ? n0.z : n1.y;
+                const float e1x = negx ? n2.y : n1.z, x1x = negx ? n1.z : n2.y;
+                const float e1y = negy ? n2.z : n1.w, x1y = negy ? n1.w : n2.z;
+                const float e1z = negz ? n2.w : n2.x, x1z = negz ? n2.x : n2.w;
+                const float tn0 = fmaxf(fmaxf(fmaf(e0x, ix, cnx), fmaf(e0y, iy, cny)), fmaxf(fmaf(e0z, iz, cnz), 0.f));
+                const float tf0 = fminf(fminf(fmaf(x0x, ix, cfx), fmaf(x0y, iy, cfy)), fminf(fmaf(x0z, iz, cfz), h.t));
+                const float tn1 = fmaxf(fmaxf(fmaf(e1x, ix, cnx), fmaf(e1y, iy, cny)), fmaxf(fmaf(e1z, iz, cnz), 0.f));
+                const float tf1 = fminf(fminf(fmaf(x1x, ix, cfx), fmaf(x1y, iy, cfy)), fminf(fmaf(x1z, iz, cfz), h.t));
+                const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
+                const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                if (hit0 && hit1) {
+                    const bool first0 = tn0 <= tn1;
+                    stack[sp * kBlock + tid] = first0 ? c1 : c0;
+                    ++sp;
+                    node = first0 ? c0 : c1;
+                } else if (hit0) {
+                    node = c0;
+                } else if (hit1) {
+                    node = c1;
+                } else {
+                    if (sp == 0) break;
+                    --sp;
+                    node = stack[sp * kBlock + tid];
+                }
+            } else {
+                const uint32_t code = ~static_cast<uint32_t>(node);
+                const uint32_t first = code >> 3, cnt = code & 7u;
+                for (uint32_t k = 0; k < cnt; ++k) test_triangle(sc.triangles + 4 * static_cast<size_t>(first + k), o, d, h);
+                if (COUNT) my_tris += cnt;
+                if (sp == 0) break;
+                --sp;
+                node = stack[sp * kBlock + tid];
+            }
+        }
+        float t = h.t;
+        int code = h.id;
+        test_lights(sc, o, d, t, code);
+        hits[i] = make_float2(t, __int_as_float(code));
+    }
+    if (COUNT) {
+        atomicAdd(tc.nodes_visited, my_nodes);
+        atomicAdd(tc.tris_tested, my_tris);
+    }
+}
+
+// ----------------------------------------------------------------- shade
+
+struct Material {
+    f3 albedo;
+    float roughness, metallic, ior, anisotropy, transmission;
+};
+
+struct Frame {
+    f3 t, b, n;  // mat3(tangent, bitangent, normal) columns
+};
+__device__ __forceinline__ f3 to_world(const Frame &f, f3 l) { return (f.t * l.x + f.b * l.y) + f.n * l.z; }
+__device__ __forceinline__ f3 to_local(const Frame &f, f3 w) { return mk(dotm(f.t, w), dotm(f.b, w), dotm(f.n, w)); }
+
+// frag:154-165, :176-181
+__device__ __forceinline__ Frame frame_from_normal(f3 n)
+{
+    Frame f;
+    f.n = n;
+    if (fabsf(n.x) > fabsf(n.y)) {
+        const float l = sqrtf(n.x * n.x + n.z * n.z);
+        f.t = mk(-n.z / l, 0.f / l, n.x / l);
+    } else {
+        const float l = sqrtf(n.y * n.y + n.z * n.z);
+        f.t = mk(0.f / l, n.z / l, -n.y / l);
+    }
+    f.b = crossm(n, f.t);
+    return f;
+}
+// frag:169-174 with the shader's fixed tangent (0,0,1) (frag:816): a normal
+// parallel to z yields a NaN frame there, and so it does here.
+__device__ __forceinline__ Frame frame_from_normal_fixed_tangent(f3 n)
+{
+    Frame f;
+    f.b = normalizem(crossm(n, mk(0.f, 0.f, 1.f)));
+    f.t = crossm(f.b, n);
+    f.n = n;
+    return f;
+}
+
+// frag:197-249
+__device__ __forceinline__ float cos2_theta(f3 v) { return v.z * v.z; }
+__device__ __forceinline__ float sin2_theta(f3 v) { return fmaxf(0.f, 1.f - cos2_theta(v)); }
+__device__ __forceinline__ float tan2_theta(f3 v) { return sin2_theta(v) / cos2_theta(v); }
+__device__ __forceinline__ float clamp11(float x) { return fminf(fmaxf(x, -1.f), 1.f); }
+__device__ __forceinline__ float cos2_phi(f3 v)
+{
+    const float s = sqrtf(sin2_theta(v));
+    const float c = (s == 0.f) ? 1.f : clamp11(v.x / s);
+    return c * c;
+}
+__device__ __forceinline__ float sin2_phi(f3 v)
+{
+    const float s = sqrtf(sin2_theta(v));
+    const float c = (s == 0.f) ? 0.f : clamp11(v.y / s);
+    return c * c;
+}
+
+// frag:255-290
+__device__ __forceinline__ f3 square_to_hemisphere_cosine(float xix, float xiy)
+{
+    const float ux = xix * 2.f - 1.f, uy = xiy * 2.f - 1.f;
+    const float x2 = ux * ux, y2 = uy * uy;
+    float pr = 0.f, pa = 0.f;
+    if (x2 > y2) {
+        pr = ux;
+        pa = (kPi / 4.f) * uy / ux;
+    } else if (y2 > 0.f) {
+        pr = uy;
+        pa = (kPi / 2.f) - (kPi / 4.f) * ux / uy;
+    }
+    float s, c;
+    sincosf(pa, &s, &c);
+    f3 r;
+    r.x = c * pr;
+    r.y = s * pr;
+    r.z = sqrtf(fmaxf(0.f, 1.f - r.x * r.x - r.y * r.y));
+    return r;
+}
+
+__device__ __forceinline__ float pow5(float x)
+{
+    const float x2 = x * x;
+    return x2 * x2 * x;
+}
+
+// frag:607-634
+__device__ __forceinline__ float tr_distribution(f3 m, float ax, float ay)
+{
+    const float t2 = tan2_theta(m);
+    if (isinf(t2)) return 0.f;
+    const float c2 = cos2_theta(m);
+    const float c4 = c2 * c2;
+    const float e = (cos2_phi(m) / (ax * ax) + sin2_phi(m) / (ay * ay)) * t2;
+    return 1.f / (kPi * ax * ay * c4 * (1.f + e) * (1.f + e));
+}
+__device__ __forceinline__ float tr_lambda(f3 v, float ax, float ay)
+{
+    const float t2 = tan2_theta(v);
+    if (isinf(t2)) return 0.f;
+    const float a2 = ax * ax * cos2_phi(v) + ay * ay * sin2_phi(v);
+    return (sqrtf(1.f + a2 * t2) - 1.f) * 0.5f;
+}
+__device__ __forceinline__ float tr_masking(f3 wo, f3 wi, float ax, float ay)
+{
+    return 1.f / (1.f + tr_lambda(wo, ax, ay) + tr_lambda(wi, ax, ay));
+}
+// frag:660-665
+__device__ __forceinline__ float tr_density(f3 wo, f3 m, float ax, float ay)
+{
+    const float g1 = 1.f / (1.f + tr_lambda(wo, ax, ay));
+    return g1 * tr_distribution(m, ax, ay) * fabsf(dotm(wo, m)) / fabsf(wo.z);
+}
+// frag:636-658: visible-normal sampling; the warp of the disk sample keeps the
+// shader's mix((1 - h.z)/2, sqrt(1 - px^2), py).
+__device__ __forceinline__ f3 tr_sample_normal(f3 wo, float xix, float xiy, float ax, float ay)
+{
+    f3 h = normalizem(mk(ax * wo.x, ay * wo.y, wo.z));
+    if (h.z < 0.f) h = -h;
+    const f3 T1 = (h.z < 0.99999f) ? normalizem(crossm(mk(0.f, 0.f, 1.f), h)) : mk(1.f, 0.f, 0.f);
+    const f3 T2 = crossm(h, T1);
+    const float r = sqrtf(xix);
+    float s, c;
+    sincosf(2.f * kPi * xiy, &s, &c);
+    const float px = r * c;
+    float py = r * s;
+    const float hh = sqrtf(1.f - px * px);
+    const float lo = (1.f - h.z) / 2.f;
+    py = lo * (1.f - py) + hh * py;
+    const float pz = sqrtf(fmaxf(0.f, 1.f - (px * px + py * py)));
+    const f3 nh = (T1 * px + T2 * py) + h * pz;
+    return normalizem(mk(ax * nh.x, ay * nh.y, fmaxf(0.000001f, nh.z)));
+}
+__device__ __forceinline__ f3 reflectm(f3 I, f3 N)
+{
+    const float k = 2.f * dotm(N, I);
+    return I - N * k;
+}
+
+// One BxDF sample.  ok == false means the lobe returned vec3(0) without
+// writing a direction (frag:729,753,774,818,827): the path ends with no
+// contribution.
+struct Bxdf {
+    f3 f, wi;
+    float pdf;
+    bool ok;
+};
+
+// frag:706-721
+__device__ __forceinline__ Bxdf diffuse_bxdf(f3 n, const Material &mat, float xix, float xiy, f3 wo)
+{
+    Bxdf r;
+    if (dotm(n, wo) < 0.f) n = n * -1.f;
+    const f3 li = square_to_hemisphere_cosine(xix, xiy);
+    r.wi = to_world(frame_from_normal(n), li);
+    r.pdf = li.z * kInvPi;
+    r.f = mat.albedo * kInvPi;
+    r.ok = true;
+    return r;
+}
+
+// frag:800-837 (the 0-degree axisAngle rotation is the identity)
+__device__ __forceinline__ Bxdf microfacet_bxdf(f3 n, const Material &mat, float xix, float xiy, f3 wo)
+{
+    Bxdf r;
+    r.ok = false;
+    r.f = mk(0.f, 0.f, 0.f);
+    r.wi = mk(0.f, 0.f, 0.f);
+    r.pdf = 0.f;
+    if (dotm(n, wo) < 0.f) n = n * -1.f;
+    // frag:581-593
+    float ax = mat.roughness * mat.roughness, ay = ax;
+    if (mat.anisotropy > 0.f) {
+        const float aspect = sqrtf(1.f - mat.anisotropy * 0.9f);
+        ax /= aspect;
+        ay *= aspect;
+    }
+    const Frame fr = frame_from_normal_fixed_tangent(n);
+    const f3 lo = to_local(fr, wo);
+    if (lo.z == 0.f) return r;
+    const f3 m = tr_sample_normal(lo, xix, xiy, ax, ay);
+    const f3 li = reflectm(-lo, m);
+    if (li.z * lo.z <= 0.f) return r;
+    r.ok = true;
+    r.wi = to_world(fr, li);
+    r.pdf = tr_density(lo, m, ax, ay) / (4.f * dotm(lo, m));
+    // frag:686-702
+    const float co = fabsf(lo.z), ci = fabsf(li.z);
+    f3 hm = lo + li;
+    if (ci <= 0.f || co <= 0.f) return r;
+    if (hm.x == 0.f && hm.y == 0.f && hm.z == 0.f) return r;
+    hm = normalizem(hm);
+    const float p5 = pow5(1.f - fabsf(dotm(lo, hm)));
+    const f3 F = mk(mat.albedo.x + (1.f - mat.albedo.x) * p5, mat.albedo.y + (1.f - mat.albedo.y) * p5,
+                    mat.albedo.z + (1.f - mat.albedo.z) * p5);
+    const float dg = tr_distribution(hm, ax, ay) * tr_masking(lo, li, ax, ay);
+    const float k = 4.f * ci * co;
+    r.f = mk(dg * F.x / k, dg * F.y / k, dg * F.z / k);
+    return r;
+}
+
+// frag:549-577
+__device__ __forceinline__ bool refractm(f3 in, f3 normal, float eta, float &rel_eta, f3 &out)
+{
+    float ci = dotm(normal, in);
+    if (ci < 0.f) {
+        eta = 1.f / eta;
+        ci = -ci;
+        normal = -normal;
+    }
+    const float s2i = 1.f - ci * ci;
+    const float s2t = s2i / (eta * eta);
+    if (s2t >= 1.f) return false;
+    const float ct = sqrtf(1.f - s2t);
+    const float k = ci / eta - ct;
+    out = mk(-in.x / eta + k * normal.x, -in.y / eta + k * normal.y, -in.z / eta + k * normal.z);
+    rel_eta = eta;
+    return true;
+}
+
+// frag:723-798: rough dielectric with alpha = roughness (not squared), fixed
+// R0 = 0.05, and a 3-way lobe choice that consumes one more random number.
+__device__ __forceinline__ Bxdf dielectric_bxdf(f3 n, const Material &mat, float xix, float xiy, f3 wo, uint32_t &sx,
+                                                uint32_t &sy)
+{
+    Bxdf r;
+    r.ok = false;
+    r.f = mk(0.f, 0.f, 0.f);
+    r.wi = mk(0.f, 0.f, 0.f);
+    r.pdf = 0.f;
+    const float ax = mat.roughness, ay = mat.roughness;
+    const Frame fr = frame_from_normal(n);
+    const f3 lo = to_local(fr, wo);
+    if (lo.z == 0.f) return r;
+    const f3 m = tr_sample_normal(lo, xix, xiy, ax, ay);
+    const float R = 0.05f + (1.f - 0.05f) * pow5(1.f - fabsf(dotm(lo, m)));
+    const float T = 1.f - R;
+    const float p_reflect = R;
+    float p_transmit = T * mat.transmission;
+    float p_diffuse = T * (1.f - mat.transmission);
+    if (lo.z < 0.f) {
+        p_transmit = T;
+        p_diffuse = 0.f;
+    }
+    const float u = rng_next(sx, sy);
+    if (u <= p_reflect) {
+        const f3 li = reflectm(-lo, m);
+        if (li.z * lo.z <= 0.f) return r;
+        r.ok = true;
+        r.wi = to_world(fr, li);
+        r.pdf = tr_density(lo, m, ax, ay) / (4.f * dotm(lo, m)) * p_reflect;
+        const float v = tr_distribution(m, ax, ay) * tr_masking(lo, li, ax, ay) * R / (4.f * li.z * lo.z);
+        r.f = mk(v, v, v);
+        return r;
+    }
+    if (u <= p_reflect + p_transmit) {
+        float rel_eta = 0.f;
+        f3 li = mk(0.f, 0.f, 0.f);
+        const bool tir = !refractm(lo, m, mat.ior, rel_eta, li);
+        if (tir || lo.z * li.z > 0.f || li.z == 0.f) return r;
+        r.ok = true;
+        r.wi = to_world(fr, li);
+        const float denom = dotm(li, m) + dotm(lo, m) / rel_eta;
+        const float dm = fabsf(dotm(li, m)) / (denom * denom);
+        r.pdf = tr_density(lo, m, ax, ay) * dm * p_transmit;
+        const float v = tr_distribution(m, ax, ay) * tr_masking(lo, li, ax, ay) * T * dotm(li, m) * dotm(lo, m) /
+                        (li.z * lo.z * denom * denom);
+        r.f = mat.albedo * v;
+        return r;
+    }
+    r = diffuse_bxdf(n, mat, xix, xiy, wo);
+    r.pdf *= p_diffuse;
+    return r;
+}
+
+// frag:841-858
+__device__ __forceinline__ Bxdf sample_surface(const Material &mat, f3 n, float xix, float xiy, f3 wo, uint32_t &sx,
+                                               uint32_t &sy)
+{
+    if (mat.metallic >= rng_next(sx, sy)) return microfacet_bxdf(n, mat, xix, xiy, wo);
+    if (mat.roughness < 1.f) return dielectric_bxdf(n, mat, xix, xiy, wo, sx, sy);
+    return diffuse_bxdf(n, mat, xix, xiy, wo);
+}
+
+__device__ __forceinline__ Material load_material(const SceneView &sc, uint32_t idx)
+{
+    Material m;
+    if (idx < sc.n_materials) {
+        const float4 a = sc.materials[2 * idx], b = sc.materials[2 * idx + 1];
+        m.albedo = mk(a.x, a.y, a.z);
+        m.roughness = a.w;
+        m.metallic = b.x;
+        m.ior = b.y;
+        m.anisotropy = b.z;
+        m.transmission = b.w;
+    } else {
+        // A face without usemtl carries index 0xFFFFFFFF (scene.h:133); an
+        // out-of-range buffer-texture fetch reads zeros.
+        m.albedo = mk(0.f, 0.f, 0.f);
+        m.roughness = m.metallic = m.ior = m.anisotropy = m.transmission = 0.f;
+    }
+    return m;
+}
+
+// One bounce for every live path (frag:876-897), then wave64 compaction of
+// the survivors into the next queue: one ballot, one atomic per wave.
+__global__ void __launch_bounds__(kBlock) k_shade(SceneView sc, uint32_t bounce, uint32_t max_depth,
+                                                   const uint32_t *__restrict__ count_in, PathQueue in,
+                                                   const float2 *__restrict__ hits, PathQueue out,
+                                                   uint32_t *__restrict__ count_out, float4 *__restrict__ samples,
+                                                   unsigned long long *__restrict__ nan_counter)
+{
+    const uint32_t n = *count_in;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        float4 o0, o1, o2;
+        if (i < n) {
+            const float4 a = in.p0[i], b = in.p1[i], c = in.p2[i];
+            const float2 hit = hits[i];
+            const int code = __float_as_int(hit.y);
+            const uint32_t slot = __float_as_uint(c.w);
+            const f3 thr = mk(c.x, c.y, c.z);
+            if (code <= -2) {
+                // frag:878-882: radiance arrives; passCol = attenuation * intensity.
+                const float *rad = sc.lights[-(code + 2)].radiance;
+                f3 L = mk(thr.x * rad[0], thr.y * rad[1], thr.z * rad[2]);
+                if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) {
+                    L = mk(0.f, 0.f, 0.f);
+                    atomicAdd(nan_counter, 1ull);
+                }
+                samples[slot] = make_float4(L.x, L.y, L.z, 1.f);
+            } else if (code == -1 || bounce + 1u >= max_depth) {
+                // Escaped, or no segment left in which a light could be reached.
+                samples[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
+            } else {
+                const f3 o = mk(a.x, a.y, a.z), d = mk(a.w, b.x, b.y);
+                uint32_t sx = __float_as_uint(b.z), sy = __float_as_uint(b.w);
+                // frag:434-453
+                const float t = hit.x;
+                const f3 p = mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
+                const float4 *sp = sc.shade + 5 * static_cast<size_t>(code);
+                const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
+                const f3 v0 = mk(s0.x, s0.y, s0.z), v1 = mk(s1.x, s1.y, s1.z), v2 = mk(s2.x, s2.y, s2.z);
+                const f3 e0 = v1 - v0, e1 = v2 - v0, eP = p - v0;
+                const float e00 = dotm(e0, e0), e01 = dotm(e0, e1), e11 = dotm(e1, e1);
+                const float e0P = dotm(e0, eP), e1P = dotm(e1, eP);
+                const float inv = 1.f / (e00 * e11 - e01 * e01);
+                const float bv = (e11 * e0P - e01 * e1P) * inv;
+                const float bw = (e00 * e1P - e01 * e0P) * inv;
+                const float bu = 1.f - bv - bw;
+                const f3 n1 = mk(s0.w, s1.w, s2.w), n2 = mk(s3.x, s3.y, s3.z), n3 = mk(s4.x, s4.y, s4.z);
+                const f3 nrm = (n1 * bu + n2 * bv) + n3 * bw;  // not renormalised (frag:450)
+
+                const float xix = rng_next(sx, sy);
+                const float xiy = rng_next(sx, sy);
+                const Material mat = load_material(sc, __float_as_uint(s3.w));
+                const Bxdf r = sample_surface(mat, nrm, xix, xiy, -d, sx, sy);
+                bool dead = !r.ok;
+                f3 att = thr;
+                if (!dead) {
+                    const float cs = fabsf(dotm(nrm, r.wi));
+                    att = mk(att.x * (r.f.x * cs), att.y * (r.f.y * cs), att.z * (r.f.z * cs));
+                    if (r.pdf <= 0.f) {
+                        dead = true;
+                    } else {
+                        att = mk(att.x / r.pdf, att.y / r.pdf, att.z / r.pdf);
+                        // A path whose throughput is exactly zero can only ever add zero.
+                        if (att.x == 0.f && att.y == 0.f && att.z == 0.f) dead = true;
+                    }
+                }
+                if (dead) {
+                    samples[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
+                } else {
+                    alive = true;
+                    const f3 no = mk(p.x + r.wi.x * 0.0001f, p.y + r.wi.y * 0.0001f, p.z + r.wi.z * 0.0001f);
+                    o0 = make_float4(no.x, no.y, no.z, r.wi.x);
+                    o1 = make_float4(r.wi.y, r.wi.z, __uint_as_float(sx), __uint_as_float(sy));
+                    o2 = make_float4(att.x, att.y, att.z, c.w);
+                }
+            }
+        }
+        const unsigned long long live = __ballot(alive);
+        if (live != 0ull) {
+            const uint32_t total = static_cast<uint32_t>(__popcll(live));
+            uint32_t wave_base = 0;
+            if (lane == 0) wave_base = atomicAdd(count_out, total);
+            wave_base = __builtin_amdgcn_readfirstlane(wave_base);
+            if (alive) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
+                const uint32_t dst = wave_base + rank;
+                out.p0[dst] = o0;
+                out.p1[dst] = o1;
+                out.p2[dst] = o2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------ accumulate
+
+// sum[pixel] += each of the batch's samples of that pixel, in iteration order
+// (so the image does not depend on how many iterations share a batch).
+__global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ sum,
+                                                        uint32_t n_pixels, uint32_t n_iterations,
+                                                        const uint32_t *__restrict__ counts, uint32_t n_counts,
+                                                        unsigned long long *__restrict__ segments_total)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long s = 0;
+        for (uint32_t k = 0; k < n_counts; ++k) s += counts[k];
+        *segments_total += s;
+    }
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pixels; p += gridDim.x * kBlock) {
+        float4 acc = sum[p];
+        for (uint32_t k = 0; k < n_iterations; ++k) {
+            const float4 s = samples[static_cast<size_t>(k) * n_pixels + p];
+            acc.x += s.x;
+            acc.y += s.y;
+            acc.z += s.z;
+            acc.w += 1.f;
+        }
+        sum[p] = acc;
+    }
+}
+
+// --------------------------------------------------------------- helpers
+
+__global__ void __launch_bounds__(kBlock) k_unpack_primary(uint32_t n, PathQueue q, const float2 *__restrict__ hits,
+                                                            int32_t *ids, float *t, float *dirs)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float2 h = hits[i];
+        if (ids) ids[i] = __float_as_int(h.y);
+        if (t) t[i] = h.x;
+        if (dirs) {
+            const float4 a = q.p0[i], b = q.p1[i];
+            dirs[3 * static_cast<size_t>(i) + 0] = a.w;
+            dirs[3 * static_cast<size_t>(i) + 1] = b.x;
+            dirs[3 * static_cast<size_t>(i) + 2] = b.y;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_pack_rays(uint32_t n, const float *__restrict__ origins,
+                                                       const float *__restrict__ dirs, PathQueue q, uint32_t *count_out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = n;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const size_t k = 3 * static_cast<size_t>(i);
+        q.p0[i] = make_float4(origins[k], origins[k + 1], origins[k + 2], dirs[k]);
+        q.p1[i] = make_float4(dirs[k + 1], dirs[k + 2], 0.f, 0.f);
+        q.p2[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(i));
+    }
+}
+
+// post.frag:11-15 on the mean; output rows top-down.
+__global__ void __launch_bounds__(kBlock) k_tonemap(const float4 *__restrict__ sum, uint8_t *__restrict__ rgb,
+                                                     uint32_t width, uint32_t height)
+{
+    const uint32_t n = width * height;
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
+        const float4 s = sum[p];
+        const float inv = s.w > 0.f ? 1.f / s.w : 0.f;
+        float c[3] = {s.x * inv, s.y * inv, s.z * inv};
+        const uint32_t y = p / width, x = p - y * width;
+        uint8_t *dst = rgb + 3 * (static_cast<size_t>(height - 1u - y) * width + x);
+        for (int k = 0; k < 3; ++k) {
+            float v = c[k] / (1.f + c[k]);
+            v = powf(v, 1.f / 2.2f);
+            v = fminf(fmaxf(v, 0.f), 1.f);  // NaN -> 0
+            dst[k] = static_cast<uint8_t>(v * 255.f + 0.5f);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_sample_surface(uint32_t n, const float *__restrict__ materials,
+                                                            const float *__restrict__ normals,
+                                                            const float *__restrict__ wo, const float *__restrict__ xi,
+                                                            const uint32_t *__restrict__ seeds, float *wi_out,
+                                                            float *pdf_out, float *f_out, uint32_t *flags_out,
+                                                            uint32_t *seeds_out)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float *mp = materials + 8 * static_cast<size_t>(i);
+        Material mat;
+        mat.albedo = mk(mp[0], mp[1], mp[2]);
+        mat.roughness = mp[3];
+        mat.metallic = mp[4];
+        mat.ior = mp[5];
+        mat.anisotropy = mp[6];
+        mat.transmission = mp[7];
+        const size_t k = 3 * static_cast<size_t>(i);
+        uint32_t sx = seeds[2 * static_cast<size_t>(i)], sy = seeds[2 * static_cast<size_t>(i) + 1];
+        const Bxdf r = sample_surface(mat, mk(normals[k], normals[k + 1], normals[k + 2]), xi[2 * static_cast<size_t>(i)],
+                                      xi[2 * static_cast<size_t>(i) + 1], mk(wo[k], wo[k + 1], wo[k + 2]), sx, sy);
+        wi_out[k] = r.wi.x;
+        wi_out[k + 1] = r.wi.y;
+        wi_out[k + 2] = r.wi.z;
+        f_out[k] = r.f.x;
+        f_out[k + 1] = r.f.y;
+        f_out[k + 2] = r.f.z;
+        pdf_out[i] = r.pdf;
+        flags_out[i] = r.ok ? 0u : 1u;
+        seeds_out[2 * static_cast<size_t>(i)] = sx;
+        seeds_out[2 * static_cast<size_t>(i) + 1] = sy;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------ launchers
+
+void launch_raygen(hipStream_t s, LaunchShape g, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
+                   uint32_t n_iterations, PathQueue out, uint32_t *count_out)
+{
+    hipLaunchKernelGGL(k_raygen, dim3(g.blocks), dim3(kBlock), 0, s, cam, it_first, it_stride, n_iterations, out,
+                       count_out);
+}
+
+void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
+                   const uint32_t *count, PathQueue q, float2 *hits, TraversalCounters tc)
+{
+    if (!use_bvh) {
+        hipLaunchKernelGGL(k_extend_scan, dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits);
+        return;
+    }
+    const bool counting = tc.nodes_visited != nullptr;
+#define PT_LAUNCH_EXTEND(S)                                                                                       \
+    do {                                                                                                          \
+        if (counting)                                                                                             \
+            hipLaunchKernelGGL((k_extend_bvh<S, true>), dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits, tc); \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_extend_bvh<S, false>), dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits, tc); \
+    } while (0)
+    if (stack_entries <= 16)
+        PT_LAUNCH_EXTEND(16);
+    else if (stack_entries <= 32)
+        PT_LAUNCH_EXTEND(32);
+    else
+        PT_LAUNCH_EXTEND(64);
+#undef PT_LAUNCH_EXTEND
+}
+
+void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t bounce, uint32_t max_depth,
+                  const uint32_t *count_in, PathQueue in, const float2 *hits, PathQueue out, uint32_t *count_out,
+                  float4 *samples, unsigned long long *nan_counter)
+{
+    hipLaunchKernelGGL(k_shade, dim3(g.blocks), dim3(kBlock), 0, s, scene, bounce, max_depth, count_in, in, hits, out,
+                       count_out, samples, nan_counter);
+}
+
+void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
+                       uint32_t n_iterations, const uint32_t *counts, uint32_t n_counts,
+                       unsigned long long *segments_total)
+{
+    hipLaunchKernelGGL(k_accumulate, dim3(g.blocks), dim3(kBlock), 0, s, samples, sum, n_pixels, n_iterations, counts,
+                       n_counts, segments_total);
+}
+
+void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *hits, int32_t *ids,
+                           float *t, float *dirs)
+{
+    hipLaunchKernelGGL(k_unpack_primary, dim3(g.blocks), dim3(kBlock), 0, s, n, q, hits, ids, t, dirs);
+}
+
+void launch_pack_rays(hipStream_t s, LaunchShape g, uint32_t n, const float *origins, const float *dirs, PathQueue q,
+                      uint32_t *count_out)
+{
+    hipLaunchKernelGGL(k_pack_rays, dim3(g.blocks), dim3(kBlock), 0, s, n, origins, dirs, q, count_out);
+}
+
+void launch_tonemap(hipStream_t s, LaunchShape g, const float4 *sum, uint8_t *rgb, uint32_t width, uint32_t height)
+{
+    hipLaunchKernelGGL(k_tonemap, dim3(g.blocks), dim3(kBlock), 0, s, sum, rgb, width, height);
+}
+
+void launch_sample_surface(hipStream_t s, LaunchShape g, uint32_t n, const float *materials, const float *normals,
+                           const float *wo, const float *xi, const uint32_t *seeds, float *wi_out, float *pdf_out,
+                           float *f_out, uint32_t *flags_out, uint32_t *seeds_out)
+{
+    hipLaunchKernelGGL(k_sample_surface, dim3(g.blocks), dim3(kBlock), 0, s, n, materials, normals, wo, xi, seeds,
+                       wi_out, pdf_out, f_out, flags_out, seeds_out);
+}
+
+}  // namespace pt

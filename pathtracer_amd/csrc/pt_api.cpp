@@ -1,0 +1,921 @@
+// C ABI of the integrator (include/pathtracer_amd.h): host-side scene/camera
+// objects, device upload, and the per-batch launch sequence
+//   raygen -> [extend -> shade] x max_depth -> accumulate
+// on one HIP stream of one GPU.
+#include "../../include/pathtracer_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bvh.h"
+#include "camera.h"
+#include "device_types.h"
+#include "kernels.h"
+#include "scene.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define PT_HIP(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(PT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" +      \
+                                           __FILE__ + ":" + std::to_string(__LINE__) + ")");            \
+    } while (0)
+
+#define PT_REQUIRE(cond, msg) \
+    do {                      \
+        if (!(cond)) return fail(PT_ERR_INVALID, msg); \
+    } while (0)
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// Inverse of a column-major f32 4x4 evaluated in float64 and rounded to f32
+// (the shader inverts per ray, pathtracer.frag.glsl:102; the float64 inverse
+// reproduces its light mask).
+bool invert_mat4(const float m[16], float inv[16])
+{
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            a[r][c] = m[c * 4 + r];
+            a[r][c + 4] = (r == c) ? 1.0 : 0.0;
+        }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r)
+            if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (a[piv][col] == 0.0) return false;
+        if (piv != col)
+            for (int c = 0; c < 8; ++c) std::swap(a[piv][c], a[col][c]);
+        const double d = a[col][col];
+        for (int c = 0; c < 8; ++c) a[col][c] /= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            if (f != 0.0)
+                for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+        }
+    }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) inv[c * 4 + r] = static_cast<float>(a[r][c + 4]);
+    return true;
+}
+
+}  // namespace
+
+struct pt_scene {
+    pt::Scene scene;
+};
+
+struct pt_camera {
+    pt::Camera cam;
+    explicit pt_camera(const pt::Camera &c) : cam(c) {}
+};
+
+struct pt_renderer {
+    pt_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t n_cus = 256;
+
+    // scene on the device
+    pt::SceneView view{};
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_materials = nullptr, *d_lights = nullptr;
+    uint32_t n_nodes = 0, bvh_depth = 0, stack_entries = 16;
+    double sah_cost = 0, bvh_build_ms = 0, upload_ms = 0;
+
+    // camera
+    pt::DeviceCamera cam{};
+
+    // path state
+    uint32_t width = 0, height = 0, batch_iterations = 1;
+    size_t capacity = 0;
+    pt::PathQueue q[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    float2 *d_hits = nullptr;
+    float4 *d_samples = nullptr;
+    float4 *d_sum = nullptr;
+    uint32_t *d_counts = nullptr;             // max_depth + 1 live counts of the current batch
+    unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested
+
+    // progress
+    uint32_t rank = 0, world = 1;
+    uint64_t local_iterations = 0;  // samples per pixel rendered by this renderer since reset
+    uint64_t paths = 0;
+
+    // profile
+    double ms[4] = {0, 0, 0, 0};
+    uint64_t launches[4] = {0, 0, 0, 0};
+    struct TimedLaunch {
+        hipEvent_t begin, end;
+        int kernel;  // 0 raygen, 1 extend, 2 shade, 3 accumulate
+    };
+    std::vector<TimedLaunch> timed;
+};
+
+namespace {
+
+void free_paths(pt_renderer *r)
+{
+    for (int k = 0; k < 2; ++k) {
+        if (r->q[k].p0) (void)hipFree(r->q[k].p0);
+        if (r->q[k].p1) (void)hipFree(r->q[k].p1);
+        if (r->q[k].p2) (void)hipFree(r->q[k].p2);
+        r->q[k] = pt::PathQueue{nullptr, nullptr, nullptr};
+    }
+    if (r->d_hits) (void)hipFree(r->d_hits);
+    if (r->d_samples) (void)hipFree(r->d_samples);
+    if (r->d_sum) (void)hipFree(r->d_sum);
+    r->d_hits = nullptr;
+    r->d_samples = nullptr;
+    r->d_sum = nullptr;
+}
+
+int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
+{
+    free_paths(r);
+    r->width = width;
+    r->height = height;
+    const size_t n_pixels = static_cast<size_t>(width) * height;
+    uint32_t k = r->cfg.iterations_per_batch;
+    if (k == 0) {
+        // Enough paths in flight to keep 256 CUs busy after compaction has
+        // thinned the queue: about 8M slots, at most 16 samples per pixel.
+        k = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(16, (size_t(8) << 20) / std::max<size_t>(1, n_pixels))));
+    }
+    // Path slots are 32-bit.
+    while (k > 1 && n_pixels * k >= (size_t(1) << 31)) --k;
+    if (n_pixels * k >= (size_t(1) << 31)) return fail(PT_ERR_INVALID, "resolution too large");
+    r->batch_iterations = k;
+    r->capacity = n_pixels * k;
+    for (int b = 0; b < 2; ++b) {
+        PT_HIP(hipMalloc(&r->q[b].p0, r->capacity * sizeof(float4)));
+        PT_HIP(hipMalloc(&r->q[b].p1, r->capacity * sizeof(float4)));
+        PT_HIP(hipMalloc(&r->q[b].p2, r->capacity * sizeof(float4)));
+    }
+    PT_HIP(hipMalloc(&r->d_hits, r->capacity * sizeof(float2)));
+    PT_HIP(hipMalloc(&r->d_samples, r->capacity * sizeof(float4)));
+    PT_HIP(hipMalloc(&r->d_sum, n_pixels * sizeof(float4)));
+    PT_HIP(hipMemsetAsync(r->d_sum, 0, n_pixels * sizeof(float4), r->stream));
+    r->cam.width = width;
+    r->cam.height = height;
+    r->cam.width_f = static_cast<float>(width);
+    r->cam.height_f = static_cast<float>(height);
+    r->cam.aspect = static_cast<float>(width) / static_cast<float>(height);
+    return PT_OK;
+}
+
+pt::LaunchShape shape_for(const pt_renderer *r, size_t work_items)
+{
+    const size_t blocks_needed = (work_items + 255) / 256;
+    const size_t cap = static_cast<size_t>(r->n_cus) * 8;
+    return pt::LaunchShape{static_cast<uint32_t>(std::max<size_t>(1, std::min(blocks_needed, cap)))};
+}
+
+int reset_accumulation(pt_renderer *r)
+{
+    PT_HIP(hipMemsetAsync(r->d_sum, 0, static_cast<size_t>(r->width) * r->height * sizeof(float4), r->stream));
+    PT_HIP(hipMemsetAsync(r->d_counters, 0, 4 * sizeof(unsigned long long), r->stream));
+    r->local_iterations = 0;
+    r->paths = 0;
+    for (int k = 0; k < 4; ++k) {
+        r->ms[k] = 0;
+        r->launches[k] = 0;
+    }
+    return PT_OK;
+}
+
+// Brackets one launch with events when profiling is on.
+struct Timed {
+    pt_renderer *r;
+    int slot;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(pt_renderer *r_, int slot_) : r(r_), slot(slot_)
+    {
+        if (!r->cfg.profile) return;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, r->stream);
+    }
+    ~Timed()
+    {
+        if (!r->cfg.profile) return;
+        (void)hipEventRecord(b, r->stream);
+        r->timed.push_back(pt_renderer::TimedLaunch{a, b, slot});
+    }
+};
+
+void drain_events(pt_renderer *r)
+{
+    for (const pt_renderer::TimedLaunch &t : r->timed) {
+        float ms = 0.f;
+        if (hipEventSynchronize(t.end) == hipSuccess && hipEventElapsedTime(&ms, t.begin, t.end) == hipSuccess) {
+            r->ms[t.kernel] += ms;
+            r->launches[t.kernel] += 1;
+        }
+        (void)hipEventDestroy(t.begin);
+        (void)hipEventDestroy(t.end);
+    }
+    r->timed.clear();
+}
+
+// One batch of `kb` iterations starting at partition index `first_k`.
+int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
+{
+    const uint32_t depth = r->cfg.max_depth;
+    const size_t n_pixels = static_cast<size_t>(r->width) * r->height;
+    const size_t n_paths = n_pixels * kb;
+    const uint32_t it_first = static_cast<uint32_t>(r->rank + first_k * r->world);
+    PT_HIP(hipMemsetAsync(r->d_counts, 0, (depth + 1) * sizeof(uint32_t), r->stream));
+    pt::TraversalCounters tc{nullptr, nullptr};
+    if (r->cfg.profile) tc = pt::TraversalCounters{r->d_counters + 2, r->d_counters + 3};
+    const pt::LaunchShape g = shape_for(r, n_paths);
+    {
+        Timed t(r, 0);
+        pt::launch_raygen(r->stream, g, r->cam, it_first, r->world, kb, r->q[0], r->d_counts);
+    }
+    for (uint32_t b = 0; b < depth; ++b) {
+        const pt::PathQueue &in = r->q[b & 1], &out = r->q[(b + 1) & 1];
+        {
+            Timed t(r, 1);
+            pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, r->d_counts + b, in, r->d_hits, tc);
+        }
+        {
+            Timed t(r, 2);
+            pt::launch_shade(r->stream, g, r->view, b, depth, r->d_counts + b, in, r->d_hits, out, r->d_counts + b + 1,
+                             r->d_samples, r->d_counters + 1);
+        }
+    }
+    {
+        Timed t(r, 3);
+        pt::launch_accumulate(r->stream, shape_for(r, n_pixels), r->d_samples, r->d_sum, static_cast<uint32_t>(n_pixels), kb,
+                              r->d_counts, depth, r->d_counters);
+    }
+    PT_HIP(hipGetLastError());
+    if (r->cfg.profile) {
+        PT_HIP(hipStreamSynchronize(r->stream));
+        drain_events(r);
+    }
+    r->local_iterations += kb;
+    r->paths += n_paths;
+    return PT_OK;
+}
+
+int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
+{
+    const uint32_t T = sc->n_triangles;
+    std::vector<uint32_t> ids(static_cast<size_t>(T) * 3);
+    for (uint32_t t = 0; t < T; ++t)
+        for (int k = 0; k < 3; ++k) {
+            const float f = sc->indices[4 * static_cast<size_t>(t) + k];
+            if (!(f >= 0.f) || f >= static_cast<float>(sc->n_vertices) || f != std::floor(f))
+                return fail(PT_ERR_INVALID, "triangle " + std::to_string(t) + " references a vertex out of range");
+            ids[3 * static_cast<size_t>(t) + k] = static_cast<uint32_t>(f);
+        }
+
+    const double t0 = now_ms();
+    pt::Bvh bvh;
+    if (r->cfg.use_bvh) {
+        pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
+        if (bvh.depth > 64) return fail(PT_ERR_STATE, "BVH deeper than the largest traversal stack");
+    } else {
+        // Scan mode: triangle records in the reference's order, no tree.
+        pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
+        std::vector<pt::BvhTriangle> ordered(T);
+        for (const pt::BvhTriangle &tri : bvh.triangles) ordered[tri.original] = tri;
+        bvh.triangles.swap(ordered);
+    }
+    r->bvh_build_ms = now_ms() - t0;
+    r->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
+    r->bvh_depth = bvh.depth;
+    r->sah_cost = bvh.sah_cost;
+    r->stack_entries = bvh.depth <= 16 ? 16 : (bvh.depth <= 32 ? 32 : 64);
+
+    std::vector<pt::ShadeTriangle> shade(T);
+    for (uint32_t t = 0; t < T; ++t) {
+        const float *v[3];
+        for (int k = 0; k < 3; ++k) v[k] = sc->vertices + 3 * static_cast<size_t>(ids[3 * static_cast<size_t>(t) + k]);
+        // The reference reads the normals of record int(indices.w) (frag:437,447-449).
+        const float wf = sc->indices[4 * static_cast<size_t>(t) + 3];
+        const size_t data = (wf >= 0.f && wf < static_cast<float>(T)) ? static_cast<size_t>(wf) : t;
+        const float *n1 = sc->vertex_data + 6 * (3 * data + 0);
+        const float *n2 = sc->vertex_data + 6 * (3 * data + 1);
+        const float *n3 = sc->vertex_data + 6 * (3 * data + 2);
+        float *s = shade[t].s;
+        for (int k = 0; k < 3; ++k) {
+            s[4 * k + 0] = v[k][0];
+            s[4 * k + 1] = v[k][1];
+            s[4 * k + 2] = v[k][2];
+            s[4 * k + 3] = n1[k];
+        }
+        s[12] = n2[0];
+        s[13] = n2[1];
+        s[14] = n2[2];
+        std::memcpy(&s[15], &sc->material_map[t], 4);
+        s[16] = n3[0];
+        s[17] = n3[1];
+        s[18] = n3[2];
+        s[19] = 0.f;
+    }
+
+    std::vector<pt::DeviceLight> lights(std::max<uint32_t>(1, sc->n_lights));
+    std::memset(lights.data(), 0, lights.size() * sizeof(pt::DeviceLight));
+    for (uint32_t l = 0; l < sc->n_lights; ++l) {
+        const float *rec = sc->lights + 20 * static_cast<size_t>(l);
+        std::memcpy(lights[l].radiance, rec, 16);
+        if (!invert_mat4(rec + 4, lights[l].inv))
+            for (float &x : lights[l].inv) x = NAN;
+        // transform * (0,0,1,0) = third column
+        lights[l].normal[0] = rec[4 + 8];
+        lights[l].normal[1] = rec[4 + 9];
+        lights[l].normal[2] = rec[4 + 10];
+    }
+
+    const double t1 = now_ms();
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> int {
+        PT_HIP(hipMalloc(dst, std::max<size_t>(bytes, 64)));
+        if (bytes) PT_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return PT_OK;
+    };
+    int rc;
+    if ((rc = upload(&r->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(pt::BvhNode)))) return rc;
+    if ((rc = upload(&r->d_tris, bvh.triangles.data(), bvh.triangles.size() * sizeof(pt::BvhTriangle)))) return rc;
+    if ((rc = upload(&r->d_shade, shade.data(), shade.size() * sizeof(pt::ShadeTriangle)))) return rc;
+    if ((rc = upload(&r->d_materials, sc->materials, static_cast<size_t>(sc->n_materials) * 32))) return rc;
+    if ((rc = upload(&r->d_lights, lights.data(), lights.size() * sizeof(pt::DeviceLight)))) return rc;
+    r->upload_ms = now_ms() - t1;
+
+    r->view.nodes = static_cast<const float4 *>(r->d_nodes);
+    r->view.triangles = static_cast<const float4 *>(r->d_tris);
+    r->view.shade = static_cast<const float4 *>(r->d_shade);
+    r->view.materials = static_cast<const float4 *>(r->d_materials);
+    r->view.lights = static_cast<const pt::DeviceLight *>(r->d_lights);
+    r->view.n_triangles = T;
+    r->view.n_materials = sc->n_materials;
+    r->view.n_lights = sc->n_lights;
+    float radius = 0.f;
+    for (int a = 0; a < 3; ++a) radius = std::max(radius, std::max(std::fabs(bvh.bounds_lo[a]), std::fabs(bvh.bounds_hi[a])));
+    r->view.scene_radius = radius;
+    return PT_OK;
+}
+
+// tan(FOVY * 0.5f) with FOVY = deg * PI / 180.f in f32 (frag:306,315).
+float tan_half_fov(float degrees)
+{
+    const float fovy = degrees * 3.14159265358979323f / 180.f;
+    return std::tan(fovy * 0.5f);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pt_last_error(void) { return g_last_error.c_str(); }
+const char *pt_version(void) { return "pathtracer_amd 0.1 (gfx950)"; }
+
+int pt_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+/* ------------------------------------------------------------------ Scene */
+
+int pt_scene_load_obj(const char *obj_path, const char *mtl_root, pt_scene **out)
+{
+    PT_REQUIRE(obj_path && out, "pt_scene_load_obj: null argument");
+    pt_scene *s = new (std::nothrow) pt_scene{pt::Scene(obj_path, mtl_root)};
+    if (!s) return fail(PT_ERR_INVALID, "out of memory");
+    if (!s->scene.m_error.empty() && s->scene.m_vertices.empty()) {
+        std::string msg = s->scene.m_error;
+        delete s;
+        return fail(PT_ERR_IO, msg);
+    }
+    *out = s;
+    return PT_OK;
+}
+
+int pt_scene_create_default(pt_scene **out)
+{
+    PT_REQUIRE(out, "pt_scene_create_default: null argument");
+    *out = new pt_scene{pt::Scene()};
+    return PT_OK;
+}
+
+int pt_scene_from_desc(const pt_scene_desc *d, pt_scene **out)
+{
+    PT_REQUIRE(d && out, "pt_scene_from_desc: null argument");
+    pt_scene *s = new pt_scene{pt::Scene()};
+    pt::Scene &sc = s->scene;
+    sc.m_vertices.assign(reinterpret_cast<const pt::Vec3 *>(d->vertices),
+                         reinterpret_cast<const pt::Vec3 *>(d->vertices) + d->n_vertices);
+    sc.m_indices.assign(reinterpret_cast<const pt::Vec4 *>(d->indices),
+                        reinterpret_cast<const pt::Vec4 *>(d->indices) + d->n_triangles);
+    sc.m_vertexData.assign(reinterpret_cast<const pt::Scene::VertexData *>(d->vertex_data),
+                           reinterpret_cast<const pt::Scene::VertexData *>(d->vertex_data) + 3 * static_cast<size_t>(d->n_triangles));
+    sc.m_lights.assign(reinterpret_cast<const pt::Scene::Light *>(d->lights),
+                       reinterpret_cast<const pt::Scene::Light *>(d->lights) + d->n_lights);
+    sc.m_lightCount[0] = d->n_lights;
+    sc.m_materials.assign(reinterpret_cast<const pt::Scene::Material *>(d->materials),
+                          reinterpret_cast<const pt::Scene::Material *>(d->materials) + d->n_materials);
+    sc.m_materialMap.assign(d->material_map, d->material_map + d->n_triangles);
+    *out = s;
+    return PT_OK;
+}
+
+void pt_scene_destroy(pt_scene *scene) { delete scene; }
+
+int pt_scene_get_desc(const pt_scene *scene, pt_scene_desc *d)
+{
+    PT_REQUIRE(scene && d, "pt_scene_get_desc: null argument");
+    const pt::Scene &sc = scene->scene;
+    d->vertices = sc.m_vertices.empty() ? nullptr : &sc.m_vertices[0].x;
+    d->n_vertices = static_cast<uint32_t>(sc.m_vertices.size());
+    d->indices = sc.m_indices.empty() ? nullptr : &sc.m_indices[0].x;
+    d->n_triangles = static_cast<uint32_t>(sc.m_indices.size());
+    d->vertex_data = sc.m_vertexData.empty() ? nullptr : &sc.m_vertexData[0].normal.x;
+    d->lights = sc.m_lights.empty() ? nullptr : sc.m_lights[0].radiance;
+    d->n_lights = std::min<uint32_t>(sc.m_lightCount[0], static_cast<uint32_t>(sc.m_lights.size()));
+    d->materials = sc.m_materials.empty() ? nullptr : &sc.m_materials[0].albedo.x;
+    d->n_materials = static_cast<uint32_t>(sc.m_materials.size());
+    d->material_map = sc.m_materialMap.empty() ? nullptr : sc.m_materialMap.data();
+    return PT_OK;
+}
+
+int pt_light_make(const float radiance[3], const float position[3], const float rotation[3], const float scale[3],
+                  float out_light[20])
+{
+    PT_REQUIRE(radiance && position && rotation && scale && out_light, "pt_light_make: null argument");
+    pt::Scene::Light l(pt::make3(radiance[0], radiance[1], radiance[2]), pt::make3(position[0], position[1], position[2]),
+                       pt::make3(rotation[0], rotation[1], rotation[2]), pt::make3(scale[0], scale[1], scale[2]));
+    std::memcpy(out_light, &l, sizeof(l));
+    return PT_OK;
+}
+
+int pt_scene_set_lights(pt_scene *scene, const float *lights, uint32_t n)
+{
+    PT_REQUIRE(scene && (lights || n == 0), "pt_scene_set_lights: null argument");
+    scene->scene.m_lights.assign(reinterpret_cast<const pt::Scene::Light *>(lights),
+                                 reinterpret_cast<const pt::Scene::Light *>(lights) + n);
+    scene->scene.m_lightCount[0] = n;
+    return PT_OK;
+}
+
+int pt_scene_set_default_light(pt_scene *scene)
+{
+    PT_REQUIRE(scene, "pt_scene_set_default_light: null argument");
+    scene->scene.setDefaultLight();
+    return PT_OK;
+}
+
+int pt_scene_instance_lattice(const pt_scene *base, uint32_t room_triangles, uint32_t n, pt_scene **out)
+{
+    PT_REQUIRE(base && out && n >= 1, "pt_scene_instance_lattice: bad argument");
+    const size_t nv = base->scene.m_vertices.size() * (static_cast<size_t>(n) * n * n + 1);
+    PT_REQUIRE(nv < (size_t(1) << 24), "pt_scene_instance_lattice: more than 2^24 vertices");
+    *out = new pt_scene{pt::Scene::instanceLattice(base->scene, room_triangles, n)};
+    return PT_OK;
+}
+
+/* ----------------------------------------------------------------- Camera */
+
+int pt_camera_create(const float eye[3], const float focus[3], uint32_t width, uint32_t height, pt_camera **out)
+{
+    PT_REQUIRE(eye && focus && out, "pt_camera_create: null argument");
+    *out = new pt_camera(pt::Camera(pt::make3(eye[0], eye[1], eye[2]), pt::make3(focus[0], focus[1], focus[2]), width, height));
+    return PT_OK;
+}
+void pt_camera_destroy(pt_camera *cam) { delete cam; }
+int pt_camera_look_at(pt_camera *cam, const float focus[3], const float *eye)
+{
+    PT_REQUIRE(cam && focus, "pt_camera_look_at: null argument");
+    if (eye)
+        cam->cam.lookAt(pt::make3(focus[0], focus[1], focus[2]), pt::make3(eye[0], eye[1], eye[2]));
+    else
+        cam->cam.lookAt(pt::make3(focus[0], focus[1], focus[2]));
+    return PT_OK;
+}
+int pt_camera_move(pt_camera *cam, const float o[3])
+{
+    PT_REQUIRE(cam && o, "pt_camera_move: null argument");
+    cam->cam.move(pt::make3(o[0], o[1], o[2]));
+    return PT_OK;
+}
+int pt_camera_pan(pt_camera *cam, float dx, float dy)
+{
+    PT_REQUIRE(cam, "pt_camera_pan: null argument");
+    cam->cam.pan(dx, dy);
+    return PT_OK;
+}
+int pt_camera_orbit(pt_camera *cam, float dx, float dy)
+{
+    PT_REQUIRE(cam, "pt_camera_orbit: null argument");
+    cam->cam.orbit(dx, dy);
+    return PT_OK;
+}
+int pt_camera_zoom(pt_camera *cam, float scale)
+{
+    PT_REQUIRE(cam, "pt_camera_zoom: null argument");
+    cam->cam.zoom(scale);
+    return PT_OK;
+}
+int pt_camera_update(pt_camera *cam)
+{
+    PT_REQUIRE(cam, "pt_camera_update: null argument");
+    cam->cam.update();
+    return PT_OK;
+}
+int pt_camera_get(const pt_camera *cam, float out[15], uint32_t res[2])
+{
+    PT_REQUIRE(cam && out, "pt_camera_get: null argument");
+    const pt::Vec3 v[5] = {cam->cam.m_eye, cam->cam.m_focus, cam->cam.m_forward, cam->cam.m_up, cam->cam.m_right};
+    for (int i = 0; i < 5; ++i)
+        for (int k = 0; k < 3; ++k) out[3 * i + k] = v[i][k];
+    if (res) {
+        res[0] = cam->cam.m_resolution[0];
+        res[1] = cam->cam.m_resolution[1];
+    }
+    return PT_OK;
+}
+
+/* --------------------------------------------------------------- Renderer */
+
+void pt_config_default(pt_config *cfg)
+{
+    if (!cfg) return;
+    cfg->width = 1280;
+    cfg->height = 720;
+    cfg->max_depth = 10;
+    cfg->fov_y_degrees = 19.5f;
+    cfg->device = -1;
+    cfg->use_bvh = 1;
+    cfg->iterations_per_batch = 0;
+    cfg->profile = 0;
+}
+
+int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer **out)
+{
+    PT_REQUIRE(scene && out, "pt_create: null argument");
+    pt_config cfg;
+    if (cfg_in)
+        cfg = *cfg_in;
+    else
+        pt_config_default(&cfg);
+    PT_REQUIRE(cfg.width >= 1 && cfg.height >= 1, "pt_create: empty resolution");
+    PT_REQUIRE(cfg.max_depth >= 1 && cfg.max_depth <= 1024, "pt_create: max_depth out of range");
+    PT_REQUIRE(scene->n_triangles == 0 || (scene->vertices && scene->indices && scene->vertex_data && scene->material_map),
+               "pt_create: scene arrays missing");
+    PT_REQUIRE(scene->n_triangles < (1u << 28), "pt_create: too many triangles");
+    PT_REQUIRE(scene->n_lights == 0 || scene->lights, "pt_create: lights missing");
+    PT_REQUIRE(scene->n_materials == 0 || scene->materials, "pt_create: materials missing");
+
+    int ndev = 0;
+    PT_HIP(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(PT_ERR_DEVICE, "no HIP device visible");
+    int device = cfg.device;
+    if (device < 0) PT_HIP(hipGetDevice(&device));
+    if (device >= ndev) return fail(PT_ERR_INVALID, "pt_create: device ordinal out of range");
+    PT_HIP(hipSetDevice(device));
+
+    pt_renderer *r = new pt_renderer();
+    r->cfg = cfg;
+    r->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        r->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
+    int rc = PT_OK;
+    auto bail = [&](int code) {
+        std::string keep = g_last_error;
+        pt_destroy(r);
+        g_last_error = keep;
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(PT_ERR_DEVICE, "hipStreamCreate failed"));
+    if ((rc = upload_scene(r, scene)) != PT_OK) return bail(rc);
+    if (hipMalloc(&r->d_counts, (cfg.max_depth + 1) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&r->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess)
+        return bail(fail(PT_ERR_DEVICE, "hipMalloc failed"));
+    if ((rc = alloc_paths(r, cfg.width, cfg.height)) != PT_OK) return bail(rc);
+    r->cam.tan_half_fov = tan_half_fov(cfg.fov_y_degrees);
+
+    // The pose main.cpp:126 hard-codes, until pt_set_camera says otherwise.
+    pt::Camera def(pt::make3(0.f, 1.5f, 15.f), pt::make3(0.f, -0.25f, 0.f), cfg.width, cfg.height);
+    def.update();
+    for (int k = 0; k < 3; ++k) {
+        r->cam.eye[k] = def.m_eye[k];
+        r->cam.forward[k] = def.m_forward[k];
+        r->cam.up[k] = def.m_up[k];
+        r->cam.right[k] = def.m_right[k];
+    }
+    if ((rc = reset_accumulation(r)) != PT_OK) return bail(rc);
+    if (hipStreamSynchronize(r->stream) != hipSuccess) return bail(fail(PT_ERR_DEVICE, "initial synchronise failed"));
+    *out = r;
+    return PT_OK;
+}
+
+void pt_destroy(pt_renderer *r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    drain_events(r);
+    free_paths(r);
+    void *bufs[] = {r->d_nodes, r->d_tris, r->d_shade, r->d_materials, r->d_lights, r->d_counts, r->d_counters};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+int pt_set_camera(pt_renderer *r, const float eye[3], const float forward[3], const float up[3], const float right[3])
+{
+    PT_REQUIRE(r && eye && forward && up && right, "pt_set_camera: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    for (int k = 0; k < 3; ++k) {
+        r->cam.eye[k] = eye[k];
+        r->cam.forward[k] = forward[k];
+        r->cam.up[k] = up[k];
+        r->cam.right[k] = right[k];
+    }
+    return reset_accumulation(r);
+}
+
+int pt_resize(pt_renderer *r, uint32_t width, uint32_t height)
+{
+    PT_REQUIRE(r && width >= 1 && height >= 1, "pt_resize: bad argument");
+    PT_HIP(hipSetDevice(r->device));
+    PT_HIP(hipStreamSynchronize(r->stream));
+    int rc = alloc_paths(r, width, height);
+    if (rc != PT_OK) return rc;
+    r->cfg.width = width;
+    r->cfg.height = height;
+    return reset_accumulation(r);
+}
+
+int pt_reset(pt_renderer *r)
+{
+    PT_REQUIRE(r, "pt_reset: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    return reset_accumulation(r);
+}
+
+int pt_set_partition(pt_renderer *r, uint32_t rank, uint32_t world)
+{
+    PT_REQUIRE(r && world >= 1 && rank < world, "pt_set_partition: need rank < world");
+    PT_HIP(hipSetDevice(r->device));
+    r->rank = rank;
+    r->world = world;
+    return reset_accumulation(r);
+}
+
+int pt_render(pt_renderer *r, uint32_t n_iterations)
+{
+    PT_REQUIRE(r, "pt_render: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    uint32_t left = n_iterations;
+    while (left > 0) {
+        const uint32_t kb = std::min(left, r->batch_iterations);
+        const uint64_t last = r->rank + (r->local_iterations + kb - 1) * static_cast<uint64_t>(r->world);
+        if (last > 0xFFFFFFFEull) return fail(PT_ERR_STATE, "iteration counter would overflow 32 bits");
+        int rc = render_batch(r, r->local_iterations, kb);
+        if (rc != PT_OK) return rc;
+        left -= kb;
+    }
+    return PT_OK;
+}
+
+int pt_synchronize(pt_renderer *r)
+{
+    PT_REQUIRE(r, "pt_synchronize: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    PT_HIP(hipStreamSynchronize(r->stream));
+    return PT_OK;
+}
+
+int pt_read_sum(pt_renderer *r, float *rgba)
+{
+    PT_REQUIRE(r && rgba, "pt_read_sum: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    PT_HIP(hipMemcpyAsync(rgba, r->d_sum, static_cast<size_t>(r->width) * r->height * sizeof(float4), hipMemcpyDeviceToHost,
+                          r->stream));
+    PT_HIP(hipStreamSynchronize(r->stream));
+    return PT_OK;
+}
+
+int pt_read_radiance(pt_renderer *r, float *rgba)
+{
+    int rc = pt_read_sum(r, rgba);
+    if (rc != PT_OK) return rc;
+    const size_t n = static_cast<size_t>(r->width) * r->height;
+    for (size_t p = 0; p < n; ++p) {
+        const float cnt = rgba[4 * p + 3];
+        const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+        rgba[4 * p + 0] *= inv;
+        rgba[4 * p + 1] *= inv;
+        rgba[4 * p + 2] *= inv;
+    }
+    return PT_OK;
+}
+
+int pt_read_tonemapped(pt_renderer *r, uint8_t *rgb)
+{
+    PT_REQUIRE(r && rgb, "pt_read_tonemapped: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    const size_t n = static_cast<size_t>(r->width) * r->height;
+    uint8_t *d = nullptr;
+    PT_HIP(hipMalloc(&d, 3 * n));
+    pt::launch_tonemap(r->stream, shape_for(r, n), r->d_sum, d, r->width, r->height);
+    hipError_t e = hipMemcpyAsync(rgb, d, 3 * n, hipMemcpyDeviceToHost, r->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    (void)hipFree(d);
+    PT_HIP(e);
+    return PT_OK;
+}
+
+int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, float *dirs)
+{
+    PT_REQUIRE(r && (ids || t || dirs), "pt_read_hit_ids: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    PT_HIP(hipStreamSynchronize(r->stream));
+    const size_t n = static_cast<size_t>(r->width) * r->height;
+    int32_t *d_ids = nullptr;
+    float *d_t = nullptr, *d_dirs = nullptr;
+    uint32_t *d_count = nullptr;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() {
+        if (d_ids) (void)hipFree(d_ids);
+        if (d_t) (void)hipFree(d_t);
+        if (d_dirs) (void)hipFree(d_dirs);
+        if (d_count) (void)hipFree(d_count);
+    };
+#define PT_TRY(expr)                \
+    do {                            \
+        e = (expr);                 \
+        if (e != hipSuccess) {      \
+            cleanup();              \
+            PT_HIP(e);              \
+        }                           \
+    } while (0)
+    PT_TRY(hipMalloc(&d_count, sizeof(uint32_t)));
+    if (ids) PT_TRY(hipMalloc(&d_ids, n * sizeof(int32_t)));
+    if (t) PT_TRY(hipMalloc(&d_t, n * sizeof(float)));
+    if (dirs) PT_TRY(hipMalloc(&d_dirs, 3 * n * sizeof(float)));
+    const pt::LaunchShape g = shape_for(r, n);
+    pt::launch_raygen(r->stream, g, r->cam, iteration, 1, 1, r->q[0], d_count);
+    pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, d_count, r->q[0], r->d_hits,
+                      pt::TraversalCounters{nullptr, nullptr});
+    pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(n), r->q[0], r->d_hits, d_ids, d_t, d_dirs);
+    PT_TRY(hipGetLastError());
+    if (ids) PT_TRY(hipMemcpyAsync(ids, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
+    if (t) PT_TRY(hipMemcpyAsync(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
+    if (dirs) PT_TRY(hipMemcpyAsync(dirs, d_dirs, 3 * n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
+    PT_TRY(hipStreamSynchronize(r->stream));
+    cleanup();
+    return PT_OK;
+}
+
+int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float *dirs, float *t, int32_t *ids)
+{
+    PT_REQUIRE(r && (n == 0 || (origins && dirs)), "pt_trace_rays: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    PT_HIP(hipStreamSynchronize(r->stream));
+    if (n == 0) return PT_OK;
+    const size_t chunk_max = r->capacity;
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    int32_t *d_ids = nullptr;
+    uint32_t *d_count = nullptr;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() {
+        if (d_o) (void)hipFree(d_o);
+        if (d_d) (void)hipFree(d_d);
+        if (d_t) (void)hipFree(d_t);
+        if (d_ids) (void)hipFree(d_ids);
+        if (d_count) (void)hipFree(d_count);
+    };
+    const size_t m = static_cast<size_t>(std::min<uint64_t>(n, chunk_max));
+    PT_TRY(hipMalloc(&d_o, 3 * m * sizeof(float)));
+    PT_TRY(hipMalloc(&d_d, 3 * m * sizeof(float)));
+    PT_TRY(hipMalloc(&d_t, m * sizeof(float)));
+    PT_TRY(hipMalloc(&d_ids, m * sizeof(int32_t)));
+    PT_TRY(hipMalloc(&d_count, sizeof(uint32_t)));
+    for (uint64_t off = 0; off < n; off += m) {
+        const size_t c = static_cast<size_t>(std::min<uint64_t>(m, n - off));
+        PT_TRY(hipMemcpyAsync(d_o, origins + 3 * off, 3 * c * sizeof(float), hipMemcpyHostToDevice, r->stream));
+        PT_TRY(hipMemcpyAsync(d_d, dirs + 3 * off, 3 * c * sizeof(float), hipMemcpyHostToDevice, r->stream));
+        const pt::LaunchShape g = shape_for(r, c);
+        pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], d_count);
+        pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, d_count, r->q[0], r->d_hits,
+                          pt::TraversalCounters{nullptr, nullptr});
+        pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(c), r->q[0], r->d_hits, d_ids, d_t, nullptr);
+        PT_TRY(hipGetLastError());
+        if (t) PT_TRY(hipMemcpyAsync(t + off, d_t, c * sizeof(float), hipMemcpyDeviceToHost, r->stream));
+        if (ids) PT_TRY(hipMemcpyAsync(ids + off, d_ids, c * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
+        PT_TRY(hipStreamSynchronize(r->stream));
+    }
+    cleanup();
+    return PT_OK;
+}
+
+int pt_sample_surface(pt_renderer *r, uint64_t n, const float *materials, const float *normals, const float *wo,
+                      const float *xi, const uint32_t *seeds, float *wi_out, float *pdf_out, float *f_out,
+                      uint32_t *flags_out, uint32_t *seeds_out)
+{
+    PT_REQUIRE(r && materials && normals && wo && xi && seeds && wi_out && pdf_out && f_out && flags_out && seeds_out,
+               "pt_sample_surface: null argument");
+    PT_REQUIRE(n < (1ull << 31), "pt_sample_surface: too many records");
+    PT_HIP(hipSetDevice(r->device));
+    if (n == 0) return PT_OK;
+    // One device block: inputs then outputs, all 4-byte elements.
+    const size_t in_words = n * (8 + 3 + 3 + 2 + 2), out_words = n * (3 + 1 + 3 + 1 + 2);
+    float *d = nullptr;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() {
+        if (d) (void)hipFree(d);
+    };
+    PT_TRY(hipMalloc(&d, (in_words + out_words) * 4));
+    float *d_mat = d, *d_nrm = d_mat + 8 * n, *d_wo = d_nrm + 3 * n, *d_xi = d_wo + 3 * n;
+    uint32_t *d_seed = reinterpret_cast<uint32_t *>(d_xi + 2 * n);
+    float *d_wi = reinterpret_cast<float *>(d_seed + 2 * n), *d_pdf = d_wi + 3 * n, *d_f = d_pdf + n;
+    uint32_t *d_flags = reinterpret_cast<uint32_t *>(d_f + 3 * n), *d_seed_out = d_flags + n;
+    PT_TRY(hipMemcpyAsync(d_mat, materials, 8 * n * 4, hipMemcpyHostToDevice, r->stream));
+    PT_TRY(hipMemcpyAsync(d_nrm, normals, 3 * n * 4, hipMemcpyHostToDevice, r->stream));
+    PT_TRY(hipMemcpyAsync(d_wo, wo, 3 * n * 4, hipMemcpyHostToDevice, r->stream));
+    PT_TRY(hipMemcpyAsync(d_xi, xi, 2 * n * 4, hipMemcpyHostToDevice, r->stream));
+    PT_TRY(hipMemcpyAsync(d_seed, seeds, 2 * n * 4, hipMemcpyHostToDevice, r->stream));
+    pt::launch_sample_surface(r->stream, shape_for(r, n), static_cast<uint32_t>(n), d_mat, d_nrm, d_wo, d_xi, d_seed, d_wi,
+                              d_pdf, d_f, d_flags, d_seed_out);
+    PT_TRY(hipGetLastError());
+    PT_TRY(hipMemcpyAsync(wi_out, d_wi, 3 * n * 4, hipMemcpyDeviceToHost, r->stream));
+    PT_TRY(hipMemcpyAsync(pdf_out, d_pdf, n * 4, hipMemcpyDeviceToHost, r->stream));
+    PT_TRY(hipMemcpyAsync(f_out, d_f, 3 * n * 4, hipMemcpyDeviceToHost, r->stream));
+    PT_TRY(hipMemcpyAsync(flags_out, d_flags, n * 4, hipMemcpyDeviceToHost, r->stream));
+    PT_TRY(hipMemcpyAsync(seeds_out, d_seed_out, 2 * n * 4, hipMemcpyDeviceToHost, r->stream));
+    PT_TRY(hipStreamSynchronize(r->stream));
+    cleanup();
+    return PT_OK;
+}
+#undef PT_TRY
+
+int pt_sum_device_ptr(pt_renderer *r, void **dev_ptr)
+{
+    PT_REQUIRE(r && dev_ptr, "pt_sum_device_ptr: null argument");
+    *dev_ptr = r->d_sum;
+    return PT_OK;
+}
+
+int pt_get_stats(pt_renderer *r, pt_stats *s)
+{
+    PT_REQUIRE(r && s, "pt_get_stats: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    PT_HIP(hipStreamSynchronize(r->stream));
+    drain_events(r);
+    unsigned long long c[4] = {0, 0, 0, 0};
+    PT_HIP(hipMemcpy(c, r->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    std::memset(s, 0, sizeof(*s));
+    s->iterations = r->local_iterations;
+    s->paths = r->paths;
+    s->segments = c[0];
+    s->nan_samples = c[1];
+    s->nodes_visited = c[2];
+    s->tris_tested = c[3];
+    s->n_triangles = r->view.n_triangles;
+    s->n_nodes = r->n_nodes;
+    s->bvh_depth = r->bvh_depth;
+    s->stack_entries = r->stack_entries;
+    s->bvh_build_ms = r->bvh_build_ms;
+    s->upload_ms = r->upload_ms;
+    s->ms_raygen = r->ms[0];
+    s->ms_extend = r->ms[1];
+    s->ms_shade = r->ms[2];
+    s->ms_accumulate = r->ms[3];
+    s->launches_raygen = r->launches[0];
+    s->launches_extend = r->launches[1];
+    s->launches_shade = r->launches[2];
+    s->launches_accumulate = r->launches[3];
+    s->sah_cost = r->sah_cost;
+    return PT_OK;
+}
+
+}  // extern "C"
