@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the wavefront integrator over one batch of synthetic
+work: `--spp-per-step` iterations (samples per pixel) of the scene at
+1920x1080, max depth 8, on every rank (weak scaling: rank g of G renders
+iterations g, g+G, ...).  The per-GPU radiance sums are combined by one
+reduce (RCCL when G > 1) at the end of the timed region.  Rank 0 prints ONE
+JSON line; `value` is whole-job Mpaths/s.
+
+Outside the timed region the same command also
+  * checks the primary hit-ID buffer against the reference's (llvmpipe fixture),
+  * re-runs the workload with per-kernel HIP-event timing for the roofline,
+  * times the CPU oracle on a bounded sample of the same workload (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (spec)
+VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (spec, FMA = 2 flops)
+
+# Algorithmic HBM bytes per work item with the queue records this build uses
+# (three 16-byte lanes of path state, an 8-byte hit record, a 16-byte sample):
+EXTEND_BYTES_PER_RAY = 32 + 8          # read origin/direction lanes, write (t, id)
+SHADE_READ_BYTES = 48 + 8              # read path state + hit
+SHADE_WRITE_SURVIVOR = 48              # compacted state of a surviving path
+SAMPLE_BYTES = 16                      # one radiance sample per finished path
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=40)
+    p.add_argument("--warmup", type=int, default=4)
+    p.add_argument("--scene", default="Box")
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--depth", type=int, default=8)
+    p.add_argument("--spp-per-step", type=int, default=4)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extra", action="store_true", help="skip the secondary Veggie.obj measurement")
+    return p.parse_args()
+
+
+def load_scene(pt, name):
+    return pt.Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", name + ".npz"))
+
+
+def timed_run(pt, torch, dist, args, scene_name, rank, world, device, distributed):
+    """Returns (seconds for K steps [max over ranks], renderer)."""
+    cam = pt.Camera(resolution=(args.width, args.height))
+    r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
+                    iterations_per_batch=args.spp_per_step)
+    r.set_partition(rank, world)
+    for _ in range(args.warmup):
+        r.draw(args.spp_per_step)
+    r.synchronize()
+    r.reset()
+    r.synchronize()
+
+    def fence():
+        r.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r.draw(args.spp_per_step)
+    if distributed:
+        from pathtracer_amd import distributed as ptd
+
+        r.synchronize()
+        ptd.reduce_sum_to_root(ptd.sum_buffer_as_tensor(r, f"cuda:{device}"), 0)
+    fence()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, r
+
+
+def kernel_profile(pt, args, scene_name, device, rank, world):
+    """Same workload with every launch bracketed by HIP events on the
+    renderer's own stream (pt_config.profile)."""
+    cam = pt.Camera(resolution=(args.width, args.height))
+    r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
+                    iterations_per_batch=args.spp_per_step, profile=True)
+    r.set_partition(rank, world)
+    r.draw(args.spp_per_step)  # warm
+    r.synchronize()
+    r.reset()
+    steps = min(args.steps, 10)
+    for _ in range(steps):
+        r.draw(args.spp_per_step)
+    st = r.stats()
+    r.close()
+    return st
+
+
+def cpu_baseline(args, scene_name):
+    """The CPU oracle (plain-C restatement of the reference shader, linear
+    scan) on a bounded sample: one iteration of the same frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "scenes", scene_name + ".npz"))
+    sc = ob.OracleScene({k: z[k] for k in z.files})
+    import pathtracer_amd as pt
+
+    cam = pt.Camera(resolution=(args.width, args.height))
+    cam.update()
+    oc = ob.make_camera(cam.eye, cam.forward, cam.up, cam.right, args.width, args.height)
+    threads = min(16, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    n_it = 0
+    stats = None
+    while True:
+        _, stats = ob.render(sc, oc, n_it, n_it + 1, args.depth, threads)
+        n_it += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n_it >= 8:
+            break
+    paths = args.width * args.height * n_it
+    return {"value": paths / el / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "sample": f"{scene_name}.obj {args.width}x{args.height} depth {args.depth}, iterations 0..{n_it - 1} "
+                      f"({paths} paths, {el:.1f} s), oracle/pt_oracle.c with OpenMP"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch = dist = None
+    if distributed or args.gpus > 1:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        if distributed:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    import pathtracer_amd as pt
+
+    if pt.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    device = local_rank if distributed else 0
+
+    dt, r = timed_run(pt, torch, dist, args, args.scene, rank, world, device, distributed)
+    st = r.stats()
+    n_pixels = args.width * args.height
+    paths_per_rank = n_pixels * args.spp_per_step * args.steps
+    total_paths = paths_per_rank * world
+    value = total_paths / dt / 1e6
+
+    gates = {}
+    if rank == 0:
+        fx = os.path.join(ROOT, "tests", "golden", "llvmpipe", f"hit_{args.scene}_{args.width}x{args.height}_it0.npz")
+        if os.path.exists(fx):
+            ids, _, _ = r.read_hit_ids(0)
+            gates["primary_hit_ids_bit_exact_vs_reference"] = bool(np.array_equal(ids, np.load(fx)["ids"]))
+        s = r.read_sum()
+        gates["samples_per_pixel_root"] = float(s[..., 3].mean())
+        gates["image_finite"] = bool(np.isfinite(s).all())
+    r.close()
+
+    prof = kernel_profile(pt, args, args.scene, device, rank, world)
+    out = None
+    if rank == 0:
+        seg, paths = prof["segments"], prof["paths"]
+        extend_bytes = EXTEND_BYTES_PER_RAY * seg
+        shade_bytes = SHADE_READ_BYTES * seg + SHADE_WRITE_SURVIVOR * (seg - paths) + SAMPLE_BYTES * paths
+        kernels = {
+            "extend": {"ms_total": prof["ms_extend"], "launches": prof["launches_extend"], "algorithmic_bytes": extend_bytes},
+            "shade": {"ms_total": prof["ms_shade"], "launches": prof["launches_shade"], "algorithmic_bytes": shade_bytes},
+            "raygen": {"ms_total": prof["ms_raygen"], "launches": prof["launches_raygen"], "algorithmic_bytes": 48 * paths},
+            "accumulate": {"ms_total": prof["ms_accumulate"], "launches": prof["launches_accumulate"],
+                           "algorithmic_bytes": 16 * paths + 32 * n_pixels * prof["launches_accumulate"]},
+        }
+        for k in kernels.values():
+            k["avg_launch_ms"] = k["ms_total"] / max(1, k["launches"])
+            k["achieved_GBs"] = k["algorithmic_bytes"] / max(k["ms_total"], 1e-9) / 1e6
+        dom = max(("extend", "shade"), key=lambda n: kernels[n]["ms_total"])
+        achieved = kernels[dom]["achieved_GBs"]
+        # counted work for the VALU view: box tests ~ 2 x 17 flops per node, triangle test ~ 85 flops
+        flops = prof["nodes_visited"] * 44.0 + prof["tris_tested"] * 85.0 + seg * 60.0
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": kernels[dom]["avg_launch_ms"],
+                    "bytes_per_launch": kernels[dom]["algorithmic_bytes"] / max(1, kernels[dom]["launches"]),
+                    "valu_view": {"extend_counted_gflop": flops / 1e9,
+                                  "extend_tflops": flops / max(prof["ms_extend"], 1e-9) / 1e9,
+                                  "peak_tflops": VALU_PEAK_TFLOPS,
+                                  "frac": flops / max(prof["ms_extend"], 1e-9) / 1e9 / VALU_PEAK_TFLOPS},
+                    "kernels": kernels}
+        out = {
+            "metric": "Mpaths/sec at 1080p, 8 bounces, Box.obj & Veggie.obj; 1/2/4/8 MI355X",
+            "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene}.obj {args.width}x{args.height}, max depth {args.depth}, "
+                                   f"{args.spp_per_step} spp per step per GPU, default camera and light",
+                       "paths_per_step": n_pixels * args.spp_per_step * world, "parallelism": f"sample-partition x{world}"},
+            "msegments_per_s": value * st["segments"] / max(1, st["paths"]),
+            "segments_per_path": st["segments"] / max(1, st["paths"]),
+            "gates": gates,
+            "roofline": roofline,
+        }
+        timing = os.path.join(ROOT, "tests", "golden", "llvmpipe", "llvmpipe_timing.json")
+        if os.path.exists(timing):
+            out["reference_llvmpipe_container"] = json.load(open(timing))
+    if rank == 0 and not args.no_extra and args.scene != "Veggie":
+        dt2, r2 = timed_run(pt, None, None, args, "Veggie", 0, 1, device, False) if not distributed else (None, None)
+        if r2 is not None:
+            st2 = r2.stats()
+            r2.close()
+            out["veggie"] = {"value": n_pixels * args.spp_per_step * args.steps / dt2 / 1e6, "unit": "Mpaths/s",
+                             "n_gpus": 1, "ms_per_step": dt2 / args.steps * 1e3,
+                             "segments_per_path": st2["segments"] / max(1, st2["paths"])}
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args, args.scene)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -160,6 +160,14 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids_host, float
  * memory) through the same extend kernel the renderer uses. */
 int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float *dirs, float *t_host,
                   int32_t *ids_host);
+/* pt_read_hit_ids and pt_trace_rays normally add one pass to the BVH traversal:
+ * a ray that misses everything but is EXACTLY parallel (dot(n,d) == 0 in f32)
+ * to some triangle's plane is reported as hitting that triangle at t = +inf,
+ * because the reference's scan accepts it (pathtracer.frag.glsl:404-411 compare
+ * false on inf).  The render loop does not run that pass: such a hit can only
+ * produce a non-finite, dropped sample, i.e. what a miss contributes.
+ * enabled = 0 makes the readbacks use the render loop's kernel verbatim. */
+int pt_set_exact_readbacks(pt_renderer *r, uint32_t enabled);
 /* One sampleSurface evaluation per record on the GPU (pathtracer.frag.glsl:
  * 841-858) for testing the BSDF stage in isolation.  Per record: material 8
  * floats, normal 3, wo 3, xi 2, seed 2 (uint32).  Outputs: wi 3, pdf 1, f 3,
@@ -172,10 +180,20 @@ int pt_sample_surface(pt_renderer *r, uint64_t n, const float *materials, const 
  * can reduce it across GPUs without a host round trip; valid until
  * pt_resize / pt_destroy. */
 int pt_sum_device_ptr(pt_renderer *r, void **dev_ptr);
-/* Adds to the per-renderer sample counter after an external reduction wrote
- * other ranks' sums into the buffer (so that pt_read_radiance divides by the
- * global count). */
+/* The alpha lane of the sum buffer carries the per-pixel sample count, so a sum
+ * reduced across ranks still normalises correctly in pt_read_radiance. */
 int pt_get_stats(pt_renderer *r, pt_stats *stats);
+
+/* Host-only: builds the BVH the renderer would build for this scene (no GPU
+ * needed) and checks its invariants -- every triangle in exactly one leaf,
+ * every child box encloses what is below it, depth as reported.  Returns
+ * PT_ERR_STATE with a message when one is violated.  No reference counterpart
+ * (the reference scans all triangles, pathtracer.frag.glsl:391-416). */
+typedef struct {
+    uint32_t n_triangles, n_nodes, n_leaves, depth, max_leaf_size, stack_entries;
+    double sah_cost, build_ms;
+} pt_bvh_info;
+int pt_bvh_inspect(const pt_scene_desc *scene, pt_bvh_info *info);
 
 #ifdef __cplusplus
 }

@@ -222,6 +222,30 @@ void oracle_trace(const oracle_scene *sc, uint64_t n, const float *origins, cons
     free(inv);
 }
 
+/* flags[i] = 1 when some triangle gives st = NaN for ray i (the ray lies
+ * exactly in that triangle's plane: 0/0 at frag:404).  From that triangle on
+ * the shader's "st > t" is always false, so its result depends on the scan
+ * order rather than on distance; tests exclude such rays from tree-vs-scan
+ * comparisons. */
+void oracle_poisoned(const oracle_scene *sc, uint64_t n, const float *origins, const float *dirs, uint8_t *flags)
+{
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t r = 0; r < (int64_t)n; ++r) {
+        v3 o = ld3(origins + 3 * r), d = ld3(dirs + 3 * r);
+        uint8_t bad = 0;
+        for (uint32_t i = 0; i < sc->n_triangles && !bad; ++i) {
+            const float *tri = sc->indices + 4 * (size_t)i;
+            v3 v0 = ld3(sc->vertices + 3 * (size_t)(int)tri[0]);
+            v3 v1 = ld3(sc->vertices + 3 * (size_t)(int)tri[1]);
+            v3 v2 = ld3(sc->vertices + 3 * (size_t)(int)tri[2]);
+            v3 nn = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
+            float st = (dot3(nn, v0) - dot3(nn, o)) / dot3(nn, d);
+            if (st != st) bad = 1;
+        }
+        flags[r] = bad;
+    }
+}
+
 void oracle_primary(const oracle_scene *sc, const oracle_camera *cam, uint32_t iteration,
                     int32_t *ids, float *t, float *dirs)
 {

@@ -65,6 +65,9 @@ int32_t oracle_intersect(const oracle_scene *sc, const float o[3], const float d
 void oracle_trace(const oracle_scene *sc, uint64_t n, const float *origins, const float *dirs,
                   float *t_out, int32_t *id_out);
 
+/* flags[i] = 1 when some triangle yields st = NaN (0/0) for ray i. */
+void oracle_poisoned(const oracle_scene *sc, uint64_t n, const float *origins, const float *dirs, uint8_t *flags);
+
 /* Primary rays of one iteration: hit codes, t and ray directions per pixel
  * (pixel index = y*width + x, row 0 = bottom).  Any output may be NULL. */
 void oracle_primary(const oracle_scene *sc, const oracle_camera *cam, uint32_t iteration,

@@ -68,6 +68,19 @@ class Config(C.Structure):
     ]
 
 
+class BvhInfo(C.Structure):
+    _fields_ = [
+        ("n_triangles", C.c_uint32),
+        ("n_nodes", C.c_uint32),
+        ("n_leaves", C.c_uint32),
+        ("depth", C.c_uint32),
+        ("max_leaf_size", C.c_uint32),
+        ("stack_entries", C.c_uint32),
+        ("sah_cost", C.c_double),
+        ("build_ms", C.c_double),
+    ]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("iterations", C.c_uint64),
@@ -144,8 +157,10 @@ _SIGNATURES = {
         C.c_int,
         [_vp, C.c_uint64, _f32p, _f32p, _f32p, _f32p, _u32p, _f32p, _f32p, _f32p, _u32p, _u32p],
     ),
+    "pt_set_exact_readbacks": (C.c_int, [_vp, C.c_uint32]),
     "pt_sum_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "pt_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "pt_bvh_inspect": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(BvhInfo)]),
 }
 
 for _name, (_res, _args) in _SIGNATURES.items():
@@ -273,6 +288,13 @@ class Scene:
     def set_default_light(self) -> None:
         """The light main.cpp:122 installs."""
         _check(_lib.pt_scene_set_default_light(self._h))
+
+    def bvh_info(self) -> dict:
+        """Builds and validates the BVH on the host (no GPU needed)."""
+        d = self.desc()
+        info = BvhInfo()
+        _check(_lib.pt_bvh_inspect(C.byref(d), C.byref(info)))
+        return {name: getattr(info, name) for name, _ in info._fields_}
 
     def instance_lattice(self, room_triangles: int, n: int) -> "Scene":
         h = _vp()
@@ -409,6 +431,10 @@ class Renderer:
         dirs = np.zeros((self.height, self.width, 3), np.float32) if want_dirs else None
         _check(_lib.pt_read_hit_ids(self._h, iteration, _ptr(ids, _i32p), _ptr(t, _f32p), _ptr(dirs, _f32p)))
         return ids, t, dirs
+
+    def set_exact_readbacks(self, enabled: bool) -> None:
+        """False: read_hit_ids / trace_rays use the render loop's extend kernel verbatim."""
+        _check(_lib.pt_set_exact_readbacks(self._h, 1 if enabled else 0))
 
     def trace_rays(self, origins, dirs):
         o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)

@@ -43,8 +43,11 @@ void launch_raygen(hipStream_t s, LaunchShape g, DeviceCamera cam, uint32_t it_f
                    uint32_t n_iterations, PathQueue out, uint32_t *count_out);
 
 // stack_entries selects the traversal-stack instantiation (16, 32 or 64).
+// exact_parallel: also report the reference's hits at t = +inf on triangles
+// whose plane the ray is exactly parallel to (readbacks only; such a hit
+// contributes nothing to an image).
 void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
-                   const uint32_t *count, PathQueue q, float2 *hits, TraversalCounters tc);
+                   const uint32_t *count, PathQueue q, float2 *hits, TraversalCounters tc, bool exact_parallel);
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t bounce, uint32_t max_depth,
                   const uint32_t *count_in, PathQueue in, const float2 *hits, PathQueue out, uint32_t *count_out,

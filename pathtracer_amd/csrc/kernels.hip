@@ -171,7 +171,15 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, const uint
 // radius) (64 ulp of the largest coordinate involved), and a box is skipped
 // only if its padded entry distance exceeds the best t so far, never on
 // equality, so ties in other subtrees are still visited.
-template <int STACK, bool COUNT>
+//
+// EXACT adds the one case a tree cannot see: a ray exactly parallel to a
+// triangle's plane (dot(n,d) == 0 in f32) has st = +inf in the reference,
+// passes every comparison there (frag:405-411 are all false on inf/NaN) and is
+// reported as a hit at t = inf when nothing else is hit.  Such a hit carries
+// no radiance (every later value is NaN and the sample is dropped), so the
+// render loop treats it as the miss it geometrically is; the hit-buffer
+// readbacks run the extra pass so that they equal the reference's buffer.
+template <int STACK, bool COUNT, bool EXACT>
 __global__ void __launch_bounds__(kBlock) k_extend_bvh(SceneView sc, const uint32_t *__restrict__ count, PathQueue q,
                                                         float2 *__restrict__ hits, TraversalCounters tc)
 {
@@ -238,6 +246,13 @@ __global__ void __launch_bounds__(kBlock) k_extend_bvh(SceneView sc, const uint3
                 if (sp == 0) break;
                 --sp;
                 node = stack[sp * kBlock + tid];
+            }
+        }
+        if (EXACT && !(h.t < __builtin_inff())) {
+            for (uint32_t k = 0; k < sc.n_triangles; ++k) {
+                const float4 *tp = sc.triangles + 4 * static_cast<size_t>(k);
+                const f3 n = mk(tp[1].w, tp[2].w, tp[3].x);
+                if (dotm(n, d) == 0.f) test_triangle(tp, o, d, h);
             }
         }
         float t = h.t;
@@ -773,7 +788,7 @@ void launch_raygen(hipStream_t s, LaunchShape g, DeviceCamera cam, uint32_t it_f
 }
 
 void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
-                   const uint32_t *count, PathQueue q, float2 *hits, TraversalCounters tc)
+                   const uint32_t *count, PathQueue q, float2 *hits, TraversalCounters tc, bool exact_parallel)
 {
     if (!use_bvh) {
         hipLaunchKernelGGL(k_extend_scan, dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits);
@@ -782,10 +797,12 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     const bool counting = tc.nodes_visited != nullptr;
 #define PT_LAUNCH_EXTEND(S)                                                                                       \
     do {                                                                                                          \
-        if (counting)                                                                                             \
-            hipLaunchKernelGGL((k_extend_bvh<S, true>), dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits, tc); \
+        if (exact_parallel)                                                                                       \
+            hipLaunchKernelGGL((k_extend_bvh<S, false, true>), dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits, tc); \
+        else if (counting)                                                                                        \
+            hipLaunchKernelGGL((k_extend_bvh<S, true, false>), dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits, tc); \
         else                                                                                                      \
-            hipLaunchKernelGGL((k_extend_bvh<S, false>), dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits, tc); \
+            hipLaunchKernelGGL((k_extend_bvh<S, false, false>), dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits, tc); \
     } while (0)
     if (stack_entries <= 16)
         PT_LAUNCH_EXTEND(16);

@@ -117,6 +117,10 @@ struct pt_renderer {
     uint32_t *d_counts = nullptr;             // max_depth + 1 live counts of the current batch
     unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested
 
+    // pt_read_hit_ids / pt_trace_rays report hits at t = +inf on exactly
+    // parallel triangles like the reference does (see k_extend_bvh).
+    bool exact_readbacks = true;
+
     // progress
     uint32_t rank = 0, world = 1;
     uint64_t local_iterations = 0;  // samples per pixel rendered by this renderer since reset
@@ -257,7 +261,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
         const pt::PathQueue &in = r->q[b & 1], &out = r->q[(b + 1) & 1];
         {
             Timed t(r, 1);
-            pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, r->d_counts + b, in, r->d_hits, tc);
+            pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, r->d_counts + b, in, r->d_hits, tc, false);
         }
         {
             Timed t(r, 2);
@@ -785,7 +789,7 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
     const pt::LaunchShape g = shape_for(r, n);
     pt::launch_raygen(r->stream, g, r->cam, iteration, 1, 1, r->q[0], d_count);
     pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, d_count, r->q[0], r->d_hits,
-                      pt::TraversalCounters{nullptr, nullptr});
+                      pt::TraversalCounters{nullptr, nullptr}, r->exact_readbacks);
     pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(n), r->q[0], r->d_hits, d_ids, d_t, d_dirs);
     PT_TRY(hipGetLastError());
     if (ids) PT_TRY(hipMemcpyAsync(ids, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
@@ -827,7 +831,7 @@ int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float 
         const pt::LaunchShape g = shape_for(r, c);
         pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], d_count);
         pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, d_count, r->q[0], r->d_hits,
-                          pt::TraversalCounters{nullptr, nullptr});
+                          pt::TraversalCounters{nullptr, nullptr}, r->exact_readbacks);
         pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(c), r->q[0], r->d_hits, d_ids, d_t, nullptr);
         PT_TRY(hipGetLastError());
         if (t) PT_TRY(hipMemcpyAsync(t + off, d_t, c * sizeof(float), hipMemcpyDeviceToHost, r->stream));
@@ -878,10 +882,101 @@ int pt_sample_surface(pt_renderer *r, uint64_t n, const float *materials, const 
 }
 #undef PT_TRY
 
+int pt_set_exact_readbacks(pt_renderer *r, uint32_t enabled)
+{
+    PT_REQUIRE(r, "pt_set_exact_readbacks: null argument");
+    r->exact_readbacks = enabled != 0;
+    return PT_OK;
+}
+
 int pt_sum_device_ptr(pt_renderer *r, void **dev_ptr)
 {
     PT_REQUIRE(r && dev_ptr, "pt_sum_device_ptr: null argument");
     *dev_ptr = r->d_sum;
+    return PT_OK;
+}
+
+int pt_bvh_inspect(const pt_scene_desc *sc, pt_bvh_info *info)
+{
+    PT_REQUIRE(sc && info, "pt_bvh_inspect: null argument");
+    const uint32_t T = sc->n_triangles;
+    PT_REQUIRE(T == 0 || (sc->vertices && sc->indices), "pt_bvh_inspect: scene arrays missing");
+    std::vector<uint32_t> ids(static_cast<size_t>(T) * 3);
+    for (uint32_t t = 0; t < T; ++t)
+        for (int k = 0; k < 3; ++k) {
+            const float f = sc->indices[4 * static_cast<size_t>(t) + k];
+            PT_REQUIRE(f >= 0.f && f < static_cast<float>(sc->n_vertices), "pt_bvh_inspect: vertex index out of range");
+            ids[3 * static_cast<size_t>(t) + k] = static_cast<uint32_t>(f);
+        }
+    const double t0 = now_ms();
+    pt::Bvh bvh;
+    pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
+    std::memset(info, 0, sizeof(*info));
+    info->build_ms = now_ms() - t0;
+    info->n_triangles = T;
+    info->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
+    info->depth = bvh.depth;
+    info->stack_entries = bvh.depth <= 16 ? 16 : (bvh.depth <= 32 ? 32 : 64);
+    info->sah_cost = bvh.sah_cost;
+
+    // Walk the tree: boxes must enclose everything below them; leaves must
+    // partition the triangle array.
+    struct Item {
+        int32_t code;
+        float lo[3], hi[3];
+        uint32_t level;
+    };
+    std::vector<Item> todo;
+    std::vector<uint8_t> seen(T, 0);
+    Item root{0, {-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}, 1};
+    todo.push_back(root);
+    uint32_t depth = 0;
+    while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        if (it.code >= 0) {
+            if (static_cast<size_t>(it.code) >= bvh.nodes.size()) return fail(PT_ERR_STATE, "BVH child index out of range");
+            depth = std::max(depth, it.level);
+            const pt::BvhNode &n = bvh.nodes[it.code];
+            for (int c = 0; c < 2; ++c) {
+                Item ch;
+                ch.code = n.child[c];
+                ch.level = it.level + 1;
+                for (int a = 0; a < 3; ++a) {
+                    ch.lo[a] = n.q[6 * c + a];
+                    ch.hi[a] = n.q[6 * c + 3 + a];
+                }
+                const bool empty_leaf = ch.code < 0 && ((~static_cast<uint32_t>(ch.code)) & 7u) == 0;
+                if (!empty_leaf)
+                    for (int a = 0; a < 3; ++a)
+                        if (ch.lo[a] < it.lo[a] || ch.hi[a] > it.hi[a]) return fail(PT_ERR_STATE, "BVH child box leaves its parent");
+                todo.push_back(ch);
+            }
+        } else {
+            const uint32_t code = ~static_cast<uint32_t>(it.code);
+            const uint32_t first = code >> 3, cnt = code & 7u;
+            if (cnt == 0) continue;
+            info->n_leaves++;
+            info->max_leaf_size = std::max(info->max_leaf_size, cnt);
+            if (static_cast<size_t>(first) + cnt > bvh.triangles.size()) return fail(PT_ERR_STATE, "BVH leaf range out of bounds");
+            for (uint32_t k = first; k < first + cnt; ++k) {
+                const pt::BvhTriangle &tri = bvh.triangles[k];
+                if (tri.original >= T || seen[tri.original]) return fail(PT_ERR_STATE, "triangle referenced twice or out of range");
+                seen[tri.original] = 1;
+                const float *vs[3] = {tri.v0, tri.v1, tri.v2};
+                for (const float *v : vs)
+                    for (int a = 0; a < 3; ++a)
+                        if (v[a] < it.lo[a] || v[a] > it.hi[a]) return fail(PT_ERR_STATE, "triangle vertex outside its leaf box");
+                for (int k2 = 0; k2 < 3; ++k2)
+                    for (int a = 0; a < 3; ++a)
+                        if (vs[k2][a] != sc->vertices[3 * static_cast<size_t>(ids[3 * static_cast<size_t>(tri.original) + k2]) + a])
+                            return fail(PT_ERR_STATE, "triangle record does not match the scene");
+            }
+        }
+    }
+    for (uint32_t t = 0; t < T; ++t)
+        if (!seen[t]) return fail(PT_ERR_STATE, "triangle " + std::to_string(t) + " is in no leaf");
+    if (depth != bvh.depth) return fail(PT_ERR_STATE, "reported BVH depth does not match the tree");
     return PT_OK;
 }
 

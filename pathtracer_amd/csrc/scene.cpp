@@ -235,7 +235,10 @@ Scene Scene::instanceLattice(const Scene &base, uint32_t roomTriangles, uint32_t
         }
     Vec3 center = make3(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z));
     const float cell = 4.f / static_cast<float>(n);
-    const float scale = 1.f / static_cast<float>(n);
+    // 1/n, shrunk further if the content is wider than the 4-unit room so
+    // that every copy stays inside its own cell.
+    const float widest = std::max(hi.x - lo.x, std::max(hi.y - lo.y, hi.z - lo.z));
+    const float scale = (widest > 4.f ? 4.f / widest : 1.f) / static_cast<float>(n);
     const size_t cells = static_cast<size_t>(n) * n * n;
     s.m_vertices.reserve(nverts * (cells + 1));
     s.m_indices.reserve(room + content * cells);

@@ -1,0 +1,56 @@
+"""Sample-space partitioning across GPUs: one process per GPU, scene replicated,
+rank g of G renders iterations g, g+G, g+2G, ... and the per-GPU radiance sums
+are combined with ONE reduce (RCCL over xGMI when the backend is "nccl").
+
+The reference is single-GPU (one GL context); what makes this partition exact
+is that a sample depends only on (pixel, iteration index)
+(pathtracer.frag.glsl:866) and that accumulation here is a float SUM rather
+than the reference's 8-bit running average (pathtracer.frag.glsl:900-904).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def local_iterations(total_spp: int, rank: int, world: int) -> int:
+    """How many of the iterations 0..total_spp-1 fall to `rank`."""
+    if not (0 <= rank < world):
+        raise ValueError("need 0 <= rank < world")
+    return max(0, (total_spp - rank + world - 1) // world)
+
+
+def iteration_indices(total_spp: int, rank: int, world: int) -> range:
+    return range(rank, total_spp, world)
+
+
+class _DeviceArray:
+    """Exposes a raw device pointer through __cuda_array_interface__ so that
+    torch can alias it without a copy."""
+
+    def __init__(self, ptr: int, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def sum_buffer_as_tensor(renderer, device):
+    """The renderer's device-resident sum buffer (H x W x 4 float32) as a torch
+    tensor that aliases it."""
+    import torch
+
+    arr = _DeviceArray(renderer.sum_device_ptr(), (renderer.height, renderer.width, 4))
+    return torch.as_tensor(arr, device=device)
+
+
+def reduce_sum_to_root(tensor, root: int = 0):
+    """One SUM reduce of the radiance-sum buffer into `root` (in place)."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(tensor, dst=root, op=dist.ReduceOp.SUM)
+    return tensor
+
+
+def mean_image(sum_rgba: np.ndarray) -> np.ndarray:
+    """sum / count per pixel; the alpha lane carries the sample count."""
+    cnt = np.maximum(sum_rgba[..., 3:4], 1.0)
+    return sum_rgba[..., :3] / cnt

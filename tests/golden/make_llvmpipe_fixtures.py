@@ -1,0 +1,97 @@
+"""Generates the golden fixtures under tests/golden/llvmpipe/ by running the
+reference's own fragment shader on Mesa llvmpipe (oracle/llvmpipe/lp_harness.c).
+Container-only: needs /root/reference and Mesa's swrast_dri.so.  The fixtures
+are data (inputs: committed scene arrays + default camera; outputs: what the
+reference rendered); no reference source is stored.
+
+  python tests/golden/make_llvmpipe_fixtures.py ids      # primary hit buffers
+  python tests/golden/make_llvmpipe_fixtures.py images   # converged float images (minutes)
+  python tests/golden/make_llvmpipe_fixtures.py timing   # llvmpipe throughput table
+"""
+import glob
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "llvmpipe"))
+import pathtracer_amd as pt  # noqa: E402
+import run_reference as rr  # noqa: E402
+
+OUT = os.path.join(HERE, "llvmpipe")
+os.makedirs(OUT, exist_ok=True)
+
+
+def scene_and_cam(name, w, h):
+    s = pt.Scene.load_npz(os.path.join(HERE, "scenes", name + ".npz"))
+    cam = pt.Camera(resolution=(w, h))
+    cam.update()
+    return s.arrays(), (cam.eye, cam.forward, cam.up, cam.right)
+
+
+def ids_fixture(name, w, h, iteration, full):
+    a, c = scene_and_cam(name, w, h)
+    img, _ = rr.run(a, c, w, h, "ids", 1, iteration)
+    ids = img[..., 3].astype(np.int32)
+    assert np.array_equal(ids.astype(np.float32), img[..., 3])
+    out = {"ids": ids, "iteration": np.int32(iteration)}
+    if full:
+        tn, _ = rr.run(a, c, w, h, "tn", 1, iteration)
+        out["dirs_bits"] = img[..., :3].copy().view(np.uint32)
+        out["t_bits"] = tn[..., 0].copy().view(np.uint32)
+        out["normal_bits"] = tn[..., 1:].copy().view(np.uint32)
+    path = os.path.join(OUT, f"hit_{name}_{w}x{h}_it{iteration}.npz")
+    np.savez_compressed(path, **out)
+    print(name, w, h, iteration, "geometry", int((ids >= 0).sum()), "light", int((ids <= -2).sum()),
+          "miss", int((ids == -1).sum()), os.path.getsize(path), flush=True)
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "ids"
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(HERE, "scenes", "*.npz")))
+    if what == "ids":
+        for n in names:
+            ids_fixture(n, 256, 256, 0, full=n in ("Box", "Veggie", "Box_Transmission", "Box_Anisotropic"))
+        ids_fixture("Box", 256, 256, 7, full=True)
+        ids_fixture("Box", 192, 108, 3, full=True)  # non-square aspect
+        for n in ("Box", "Veggie"):
+            ids_fixture(n, 1920, 1080, 0, full=False)
+    elif what == "images":
+        jobs = [("Box", 8), ("Box", 5), ("Box_Anisotropic", 8), ("AnisotropicTest", 8), ("Box_Transmission", 8),
+                ("Box_TransmissionSphere", 8), ("Veggie", 8)]
+        for n, depth in jobs:
+            a, c = scene_and_cam(n, 256, 256)
+            t0 = time.time()
+            img, secs = rr.run(a, c, 256, 256, "float0", 256, depth)
+            path = os.path.join(OUT, f"image_{n}_256x256_spp256_depth{depth}.npz")
+            np.savez_compressed(path, mean_rgb=img[..., :3].astype(np.float32), spp=np.int32(256),
+                                depth=np.int32(depth), llvmpipe_seconds=np.float64(secs))
+            print(n, depth, "mean", img[..., :3].mean(axis=(0, 1)), "%.1fs" % (time.time() - t0),
+                  os.path.getsize(path), flush=True)
+        # the as-shipped RGBA8 feedback accumulator
+        a, c = scene_and_cam("Box", 256, 256)
+        img, secs = rr.run(a, c, 256, 256, "rgba8", 64, 10)
+        np.savez_compressed(os.path.join(OUT, "rgba8_Box_256x256_spp64_depth10.npz"), rgba8=img, spp=np.int32(64),
+                            depth=np.int32(10))
+        print("rgba8 Box mean", img[..., :3].mean(axis=(0, 1)) / 255.0, flush=True)
+    elif what == "timing":
+        rows = []
+        for n, w, h, spp, depth in [("Box", 512, 512, 64, 5), ("Box", 512, 512, 16, 10), ("Box", 256, 256, 8, 8),
+                                    ("Veggie", 256, 256, 8, 8), ("Box_Transmission", 256, 256, 8, 8),
+                                    ("Box", 1920, 1080, 2, 8), ("Veggie", 1920, 1080, 1, 8)]:
+            a, c = scene_and_cam(n, w, h)
+            _, secs = rr.run(a, c, w, h, "rgba8", spp, depth)
+            rows.append({"scene": n, "width": w, "height": h, "spp": spp, "depth": depth, "seconds": secs,
+                         "mpaths_per_s": w * h * spp / secs / 1e6, "host_cores": os.cpu_count()})
+            print(rows[-1], flush=True)
+        with open(os.path.join(OUT, "llvmpipe_timing.json"), "w") as f:
+            json.dump({"renderer": "Mesa llvmpipe (LLVM 15), reference GLSL as shipped (RGBA8 accumulation)",
+                       "measured_in": "build container", "rows": rows}, f, indent=1)
+
+
+main()

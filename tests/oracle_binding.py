@@ -132,6 +132,14 @@ def primary(scene: OracleScene, cam: OCamera, iteration=0, want_t=True, want_dir
     return ids.reshape(shape), None if t is None else t.reshape(shape), None if dirs is None else dirs.reshape(shape + (3,))
 
 
+def primary_dirs_only(scene: OracleScene, cam: OCamera, iteration=0):
+    """Ray directions of one iteration without intersecting anything."""
+    n = cam.width * cam.height
+    dirs = np.zeros((n, 3), np.float32)
+    lib().oracle_primary(C.byref(scene.c), C.byref(cam), iteration, None, None, _p(dirs))
+    return None, None, dirs.reshape(cam.height, cam.width, 3)
+
+
 def trace(scene: OracleScene, origins, dirs):
     o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
     d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
@@ -140,6 +148,18 @@ def trace(scene: OracleScene, origins, dirs):
     ids = np.zeros(n, np.int32)
     lib().oracle_trace(C.byref(scene.c), n, _p(o), _p(d), _p(t), _p(ids, _i32p))
     return t, ids
+
+
+def poisoned(scene: OracleScene, origins, dirs):
+    """True for rays lying exactly in some triangle's plane (st = 0/0 there)."""
+    o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+    flags = np.zeros(o.shape[0], np.uint8)
+    L = lib()
+    L.oracle_poisoned.restype = None
+    L.oracle_poisoned.argtypes = [C.POINTER(OScene), C.c_uint64, _f32p, _f32p, C.POINTER(C.c_uint8)]
+    L.oracle_poisoned(C.byref(scene.c), o.shape[0], _p(o), _p(d), flags.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return flags.astype(bool)
 
 
 def render(scene: OracleScene, cam: OCamera, it_begin, it_end, max_depth, nthreads=1, sum_rgba=None):

@@ -1,0 +1,177 @@
+"""Renderer semantics on the GPU (renderer.h:32-38 surface): progressive
+accumulation, reset / resize / camera changes, batch independence,
+determinism, the sample-space partition used for multi-GPU runs, and
+size-independent properties at the benchmark's full size."""
+import numpy as np
+import pytest
+
+from conftest import hit_fixture, scene_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+def _renderer(pt, name, w, h, **kw):
+    return pt.Renderer(pt.Scene.from_arrays(**scene_arrays(name)), pt.Camera(resolution=(w, h)), **kw)
+
+
+def test_progressive_accumulation_is_independent_of_call_and_batch_split(pt):
+    sums = []
+    for batch, calls in [(0, [12]), (1, [12]), (5, [7, 5]), (3, [1] * 12)]:
+        r = _renderer(pt, "Box", 96, 64, max_depth=6, iterations_per_batch=batch)
+        for c in calls:
+            r.draw(c)
+        sums.append(r.read_sum())
+        assert r.stats()["iterations"] == 12
+        r.close()
+    for s in sums[1:]:
+        assert np.array_equal(s, sums[0])
+    assert np.all(sums[0][..., 3] == 12)
+
+
+def test_deterministic_across_runs(pt):
+    a = []
+    for _ in range(2):
+        r = _renderer(pt, "Box_Transmission", 128, 96, max_depth=8)
+        r.draw(9)
+        a.append(r.read_sum())
+        r.close()
+    assert np.array_equal(a[0], a[1])
+
+
+def test_reset_resize_and_camera_change(pt):
+    r = _renderer(pt, "Box", 80, 60, max_depth=5)
+    r.draw(4)
+    first = r.read_sum()
+    r.reset()  # renderer.cpp:152-158: iteration counter back to 0
+    assert r.stats()["iterations"] == 0
+    assert not r.read_sum().any()
+    r.draw(4)
+    assert np.array_equal(r.read_sum(), first)
+
+    r.resize(40, 30)  # renderer.cpp:160-187
+    r.draw(2)
+    small = r.read_sum()
+    assert small.shape == (30, 40, 4) and np.all(small[..., 3] == 2)
+    ids, _, _ = r.read_hit_ids(0)
+    assert ids.shape == (30, 40)
+
+    r.resize(80, 60)
+    r.camera.orbit(0.4, 0.1)  # main.cpp:92-96: orbit then updateCamera -> reset
+    r.update_camera()
+    assert r.stats()["iterations"] == 0
+    r.draw(4)
+    moved = r.read_sum()
+    assert not np.array_equal(moved, first)
+    r.camera = type(r.camera)(resolution=(80, 60))
+    r.update_camera()
+    r.draw(4)
+    assert np.array_equal(r.read_sum(), first)
+    r.close()
+
+
+def test_mean_and_tonemap_readbacks(pt, ob):
+    r = _renderer(pt, "Box", 64, 48, max_depth=8)
+    r.draw(32)
+    s = r.read_sum()
+    m = r.read_radiance()
+    assert np.allclose(m[..., :3], s[..., :3] / 32.0, rtol=1e-6)
+    tm = r.read_tonemapped()
+    r.close()
+    assert tm.shape == (48, 64, 3) and tm.dtype == np.uint8
+    exp = ob.tonemap(m[..., :3])[::-1]  # file order: top row first
+    exp8 = np.clip(exp * 255.0 + 0.5, 0, 255).astype(np.uint8)
+    assert np.abs(tm.astype(int) - exp8.astype(int)).max() <= 1
+    assert tm.max() > 100  # the light is visible
+
+
+def test_partition_union_equals_single_renderer(pt):
+    """Rank g of G renders iterations g, g+G, ...: the union is the single-GPU
+    sample set, so the summed buffers agree up to fp32 addition order."""
+    spp, world = 12, 3
+    single = _renderer(pt, "Box", 96, 64, max_depth=8)
+    single.draw(spp)
+    ref = single.read_sum()
+    single.close()
+    total = np.zeros_like(ref)
+    for rank in range(world):
+        r = _renderer(pt, "Box", 96, 64, max_depth=8)
+        r.set_partition(rank, world)
+        r.draw(spp // world)
+        total += r.read_sum()
+        r.close()
+    assert np.all(total[..., 3] == spp)
+    assert np.allclose(total[..., :3], ref[..., :3], rtol=1e-5, atol=1e-6)
+
+    # a rank's samples are exactly the corresponding iterations of the single run
+    r = _renderer(pt, "Box", 96, 64, max_depth=8)
+    r.set_partition(1, 3)
+    ids_rank, _, _ = r.read_hit_ids(4)  # read_hit_ids takes the global iteration index
+    r.close()
+    s = _renderer(pt, "Box", 96, 64, max_depth=8)
+    ids_single, _, _ = s.read_hit_ids(4)
+    s.close()
+    assert np.array_equal(ids_rank, ids_single)
+
+
+def test_stats_accounting(pt):
+    r = _renderer(pt, "Box", 128, 128, max_depth=8, profile=True)
+    r.draw(8)
+    st = r.stats()
+    r.close()
+    assert st["paths"] == 128 * 128 * 8 and st["iterations"] == 8
+    assert st["paths"] <= st["segments"] <= 8 * st["paths"]
+    assert st["launches_extend"] == st["launches_shade"] and st["launches_extend"] >= 8
+    assert st["ms_extend"] > 0 and st["ms_shade"] > 0
+    assert st["nodes_visited"] > st["segments"] and st["tris_tested"] > 0
+    assert st["n_triangles"] == 155 and st["bvh_depth"] <= st["stack_entries"]
+
+
+def test_depth_one_sees_only_the_light(pt):
+    """max_depth 1: a pixel is lit iff its primary ray hits the light."""
+    r = _renderer(pt, "Box", 256, 256, max_depth=1)
+    r.draw(1)
+    s = r.read_sum()
+    ids, _, _ = r.read_hit_ids(0)
+    r.close()
+    lit = s[..., :3].sum(axis=2) > 0
+    assert np.array_equal(lit, ids == -2)
+    assert np.all(s[..., :3][lit] == 4.0)  # radiance of the default light, throughput 1
+
+
+def test_scene_without_materials_or_lights(pt):
+    """Faces without usemtl carry material 0xFFFFFFFF (scene.h:133); no light
+    means a black image, not a crash."""
+    a = scene_arrays("cube")
+    s = pt.Scene.from_arrays(a["vertices"], a["indices"], a["vertex_data"], np.zeros((0, 20), np.float32),
+                             a["materials"], a["material_map"])
+    r = pt.Renderer(s, pt.Camera(resolution=(64, 64)), max_depth=4)
+    r.draw(4)
+    out = r.read_sum()
+    r.close()
+    assert not out[..., :3].any() and np.all(out[..., 3] == 4)
+    r = _renderer(pt, "cube", 64, 64, max_depth=4)  # with the default light
+    r.draw(4)
+    assert np.isfinite(r.read_sum()).all()
+    r.close()
+
+
+def test_full_size_properties_1080p(pt):
+    """BASELINE size: hit buffer equals the reference's; every pixel gets its
+    samples; two renders agree bit for bit; light pixels converge to radiance 4
+    at depth 1."""
+    r = _renderer(pt, "Box", 1920, 1080, max_depth=8)
+    ids, _, _ = r.read_hit_ids(0)
+    assert np.array_equal(ids, hit_fixture("Box", 1920, 1080)["ids"])
+    r.draw(6)
+    a = r.read_sum()
+    st = r.stats()
+    r.reset()
+    r.draw(6)
+    b = r.read_sum()
+    r.close()
+    assert np.array_equal(a, b)
+    assert np.all(a[..., 3] == 6) and np.isfinite(a).all()
+    assert st["paths"] == 1920 * 1080 * 6
+    assert 2.0 < st["segments"] / st["paths"] < 4.5  # 16:9 frames more background than 1:1
+    mean = a[..., :3].mean(axis=(0, 1)) / 6
+    assert 0.02 < mean.min() and mean.max() < 0.12
