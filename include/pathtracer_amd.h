@@ -63,7 +63,8 @@ typedef struct {
     uint32_t use_bvh;              /* 1 = SAH BVH traversal; 0 = linear scan in the
                                       reference's triangle order (frag:391-416)         */
     uint32_t iterations_per_batch; /* samples per pixel in flight at once; 0 = auto     */
-    uint32_t profile;              /* 1 = time every kernel with HIP events (slower)    */
+    uint32_t profile;              /* bit 0: time every launch with HIP events; bit 1:
+                                      count BVH nodes / triangle tests (both slower)    */
 } pt_config;
 
 typedef struct {
@@ -71,11 +72,11 @@ typedef struct {
     uint64_t paths;           /* pixel-samples traced                                    */
     uint64_t segments;        /* rays cast (extend work items)                           */
     uint64_t nan_samples;     /* non-finite samples replaced by 0                        */
-    uint64_t nodes_visited;   /* BVH inner nodes fetched   (profile builds only)         */
-    uint64_t tris_tested;     /* triangle tests            (profile builds only)         */
+    uint64_t nodes_visited;   /* BVH inner nodes fetched   (profile bit 1)               */
+    uint64_t tris_tested;     /* triangle tests            (profile bit 1)               */
     uint32_t n_triangles, n_nodes, bvh_depth, stack_entries;
     double bvh_build_ms, upload_ms;
-    /* Sums of HIP-event durations per kernel and launch counts (profile = 1). */
+    /* Sums of HIP-event durations per kernel and launch counts (profile bit 0). */
     double ms_raygen, ms_extend, ms_shade, ms_accumulate;
     uint64_t launches_raygen, launches_extend, launches_shade, launches_accumulate;
     double sah_cost;

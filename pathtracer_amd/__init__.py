@@ -356,7 +356,7 @@ class Renderer:
 
     def __init__(self, scene: Scene, camera: Optional[Camera] = None, *, max_depth: int = 10,
                  fov_y_degrees: float = 19.5, device: int = -1, use_bvh: bool = True,
-                 iterations_per_batch: int = 0, profile: bool = False):
+                 iterations_per_batch: int = 0, profile: int = 0):
         self.scene = scene
         self.camera = camera if camera is not None else Camera()
         w, h = self.camera.resolution
@@ -368,7 +368,7 @@ class Renderer:
         cfg.device = device
         cfg.use_bvh = 1 if use_bvh else 0
         cfg.iterations_per_batch = iterations_per_batch
-        cfg.profile = 1 if profile else 0
+        cfg.profile = int(profile)  # bit 0: per-launch HIP-event timing; bit 1: traversal counters
         self.config = cfg
         self._h = _vp()
         d = scene.desc()

@@ -215,14 +215,14 @@ struct Timed {
     hipEvent_t a = nullptr, b = nullptr;
     Timed(pt_renderer *r_, int slot_) : r(r_), slot(slot_)
     {
-        if (!r->cfg.profile) return;
+        if (!(r->cfg.profile & 1u)) return;
         (void)hipEventCreate(&a);
         (void)hipEventCreate(&b);
         (void)hipEventRecord(a, r->stream);
     }
     ~Timed()
     {
-        if (!r->cfg.profile) return;
+        if (!(r->cfg.profile & 1u)) return;
         (void)hipEventRecord(b, r->stream);
         r->timed.push_back(pt_renderer::TimedLaunch{a, b, slot});
     }
@@ -251,7 +251,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     const uint32_t it_first = static_cast<uint32_t>(r->rank + first_k * r->world);
     PT_HIP(hipMemsetAsync(r->d_counts, 0, (depth + 1) * sizeof(uint32_t), r->stream));
     pt::TraversalCounters tc{nullptr, nullptr};
-    if (r->cfg.profile) tc = pt::TraversalCounters{r->d_counters + 2, r->d_counters + 3};
+    if (r->cfg.profile & 2u) tc = pt::TraversalCounters{r->d_counters + 2, r->d_counters + 3};
     const pt::LaunchShape g = shape_for(r, n_paths);
     {
         Timed t(r, 0);
@@ -275,7 +275,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
                               r->d_counts, depth, r->d_counters);
     }
     PT_HIP(hipGetLastError());
-    if (r->cfg.profile) {
+    if (r->cfg.profile & 1u) {
         PT_HIP(hipStreamSynchronize(r->stream));
         drain_events(r);
     }

@@ -114,7 +114,7 @@ def test_partition_union_equals_single_renderer(pt):
 
 
 def test_stats_accounting(pt):
-    r = _renderer(pt, "Box", 128, 128, max_depth=8, profile=True)
+    r = _renderer(pt, "Box", 128, 128, max_depth=8, profile=3)
     r.draw(8)
     st = r.stats()
     r.close()

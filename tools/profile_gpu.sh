@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + separate PMC passes
+# over a short bench.py run.  Results land in gpurun_out/prof/<tag>/.
+# usage: tools/profile_gpu.sh TAG [bench args...]
+set -u
+TAG=${1:-r01}; shift || true
+export TMPDIR=/tmp
+OUT=gpurun_out/prof/$TAG
+mkdir -p "$OUT"
+BENCH="python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extra $*"
+run() { # name, rocprof args...
+  local name=$1; shift
+  timeout -s KILL 150 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.json" 2> "$OUT/$name.err"
+  local rc=$?
+  echo "$name rc=$rc"
+  return $rc
+}
+run kt --kernel-trace --stats || exit 1
+run pmc_fetch --pmc FETCH_SIZE || exit 1
+run pmc_write --pmc WRITE_SIZE || exit 1
+run pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum || exit 1
+run pmc_sq1 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY || exit 1
+run pmc_sq2 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE || exit 1
+python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"
