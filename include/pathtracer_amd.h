@@ -80,6 +80,11 @@ typedef struct {
     double ms_raygen, ms_extend, ms_shade, ms_accumulate;
     uint64_t launches_raygen, launches_extend, launches_shade, launches_accumulate;
     double sah_cost;
+    /* Scheduling diagnostics of the extend kernel (profile bit 1), per wave:
+     * inner-node loop iterations, lanes active in them, triangle-loop
+     * iterations, lane-triangle tests, rounds, lanes holding a ray per round,
+     * refills, rays handed out. */
+    uint64_t extend_diag[8];
 } pt_stats;
 
 const char *pt_last_error(void);

@@ -104,10 +104,13 @@ class Stats(C.Structure):
         ("launches_shade", C.c_uint64),
         ("launches_accumulate", C.c_uint64),
         ("sah_cost", C.c_double),
+        ("extend_diag", C.c_uint64 * 8),
     ]
 
     def as_dict(self) -> dict:
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        d = {name: getattr(self, name) for name, _ in self._fields_}
+        d["extend_diag"] = list(self.extend_diag)
+        return d
 
 
 _f32p = C.POINTER(C.c_float)

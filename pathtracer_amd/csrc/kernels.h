@@ -29,40 +29,67 @@ struct PathQueue {
     float4 *p2;
 };
 
+// The path queues are cut into regions of 2^shift consecutive slots.  A
+// region belongs to exactly one wave for the duration of a kernel, which
+// compacts the survivors of region r into region r of the other queue and
+// writes the region's new live count: no atomics and no ordering between
+// waves are needed, and the queue order is the same in every run.
+// counts_in/out are n_regions entries for one bounce.  Wave w handles the
+// regions perm(w), perm(w + n_waves), ... with perm(k) = k * stride mod
+// n_regions (stride coprime to n_regions), which spreads image areas with much
+// and little work evenly over the waves.
+struct Regions {
+    const uint32_t *counts_in;
+    uint32_t *counts_out;  // may be null (extend does not change counts)
+    uint32_t n_regions;
+    uint32_t stride;
+    uint32_t shift;        // log2 of the slots per region
+};
+
 struct TraversalCounters {
     unsigned long long *nodes_visited;  // may be null
     unsigned long long *tris_tested;
+    // Scheduling diagnostics of k_extend_bvh, 8 words, may be null:
+    // [0] phase-A loop iterations (per wave) [1] lanes active in them
+    // [2] phase-B triangle-loop iterations   [3] lane-triangle tests in them
+    // [4] rounds (A + B)                     [5] lanes holding a ray per round
+    // [6] refills                            [7] rays handed out by refills
+    unsigned long long *diag;
 };
 
 // Grid used by every kernel: persistent-style, grid-stride over the live count.
 struct LaunchShape {
-    uint32_t blocks;
+    uint32_t blocks;      // grid for the grid-stride kernels
+    uint32_t n_cus;       // compute units of the device
+    uint32_t wave_items;  // work available to the region kernels, in waves' worth (regions)
 };
 
+// counts_out: n_regions live counts of bounce 0.
 void launch_raygen(hipStream_t s, LaunchShape g, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
-                   uint32_t n_iterations, PathQueue out, uint32_t *count_out);
+                   uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift);
 
 // stack_entries selects the traversal-stack instantiation (16, 32 or 64).
 // exact_parallel: also report the reference's hits at t = +inf on triangles
 // whose plane the ray is exactly parallel to (readbacks only; such a hit
 // contributes nothing to an image).
 void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
-                   const uint32_t *count, PathQueue q, float2 *hits, TraversalCounters tc, bool exact_parallel);
+                   Regions regions, PathQueue q, float2 *hits, TraversalCounters tc, bool exact_parallel,
+                   uint32_t n_nodes, bool scene_in_lds);
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t bounce, uint32_t max_depth,
-                  const uint32_t *count_in, PathQueue in, const float2 *hits, PathQueue out, uint32_t *count_out,
-                  float4 *samples, unsigned long long *nan_counter);
+                  Regions regions, PathQueue in, const float2 *hits, PathQueue out, float4 *samples,
+                  unsigned long long *nan_counter);
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
-                       uint32_t n_iterations, const uint32_t *counts, uint32_t n_counts,
-                       unsigned long long *segments_total);
+                       uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
+                       uint32_t pitch, unsigned long long *segments_total);
 
 // hits -> int32 hit codes / t / directions in pixel order for one iteration.
 void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *hits, int32_t *ids,
                            float *t, float *dirs);
 
 void launch_pack_rays(hipStream_t s, LaunchShape g, uint32_t n, const float *origins, const float *dirs, PathQueue q,
-                      uint32_t *count_out);
+                      uint32_t *counts_out, uint32_t region_shift);
 
 void launch_tonemap(hipStream_t s, LaunchShape g, const float4 *sum, uint8_t *rgb, uint32_t width, uint32_t height);
 

@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 namespace pt {
 
 namespace {
@@ -57,11 +59,12 @@ __device__ __forceinline__ float rng_next(uint32_t &sx, uint32_t &sy)
 
 // frag:866 + frag:306-320.  Path slot i = k * (W*H) + pixel, pixel = y*W + x.
 __global__ void __launch_bounds__(kBlock) k_raygen(DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
-                                                    uint32_t n_iterations, PathQueue out, uint32_t *count_out)
+                                                    uint32_t n_iterations, PathQueue out, uint32_t *counts_out,
+                                                    uint32_t region_shift)
 {
+    const uint32_t region_slots = 1u << region_shift;
     const uint32_t n_pixels = cam.width * cam.height;
     const uint32_t total = n_pixels * n_iterations;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = total;
     const f3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
     const f3 fwd = mk(cam.forward[0], cam.forward[1], cam.forward[2]);
     const f3 up = mk(cam.up[0], cam.up[1], cam.up[2]);
@@ -88,10 +91,18 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceCamera cam, uint32_t it
         out.p0[i] = make_float4(eye.x, eye.y, eye.z, d.x);
         out.p1[i] = make_float4(d.y, d.z, __uint_as_float(sx), __uint_as_float(sy));
         out.p2[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(i));
+        if ((i & (region_slots - 1u)) == 0u) counts_out[i >> region_shift] = min(region_slots, total - i);
     }
 }
 
 // ---------------------------------------------------------------- extend
+
+// Region bookkeeping shared by extend and shade: which region a wave handles
+// on its k-th turn.
+__device__ __forceinline__ uint32_t region_of(const Regions &rg, uint32_t k)
+{
+    return static_cast<uint32_t>((static_cast<unsigned long long>(k) * rg.stride) % rg.n_regions);
+}
 
 struct Hit {
     float t;
@@ -144,11 +155,16 @@ __device__ __forceinline__ void test_lights(const SceneView &sc, f3 o, f3 d, flo
 }
 
 // Linear scan in the reference's triangle order (frag:391-416).
-__global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, const uint32_t *__restrict__ count, PathQueue q,
+__global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg, PathQueue q,
                                                          float2 *__restrict__ hits)
 {
-    const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    for (uint32_t k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); k < rg.n_regions; k += n_waves) {
+      const uint32_t r = region_of(rg, k);
+      const uint32_t n = rg.counts_in[r];
+      for (uint32_t j = lane; j < n; j += 64u) {
+        const uint32_t i = (r << rg.shift) + j;
         const float4 a = q.p0[i], b = q.p1[i];
         const f3 o = mk(a.x, a.y, a.z), d = mk(a.w, b.x, b.y);
         Hit h{__builtin_inff(), -1};
@@ -157,6 +173,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, const uint
         int code = h.id;
         test_lights(sc, o, d, t, code);
         hits[i] = make_float2(t, __int_as_float(code));
+      }
     }
 }
 
@@ -179,90 +196,203 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, const uint
 // no radiance (every later value is NaN and the sample is dropped), so the
 // render loop treats it as the miss it geometrically is; the hit-buffer
 // readbacks run the extra pass so that they equal the reference's buffer.
-template <int STACK, bool COUNT, bool EXACT>
-__global__ void __launch_bounds__(kBlock) k_extend_bvh(SceneView sc, const uint32_t *__restrict__ count, PathQueue q,
-                                                        float2 *__restrict__ hits, TraversalCounters tc)
+//
+// Scheduling inside a wave.  A wave owns one region of rays at a time and keeps
+// its 64 lanes fed from it: lanes whose ray has finished take the next unread
+// rays of the region (ballot + prefix rank, no atomics) once enough of them
+// are idle.  Traversal alternates two phases so that lanes do the same kind of
+// work together: (A) every lane that stands on an inner node descends until
+// it reaches a leaf or runs out of nodes, (B) the lanes standing on a leaf
+// test its triangles.
+//
+// SCENE_LDS: 0 = nodes and triangles are read from global memory (L1/L2);
+// 1 = the block keeps a copy of the node array in LDS; 2 = nodes and
+// triangles.  The host picks the largest variant that fits beside the stacks.
+template <int STACK, bool COUNT, bool EXACT, int SCENE_LDS>
+__global__ void __launch_bounds__(kBlock) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
+                                                        float2 *__restrict__ hits, TraversalCounters tc,
+                                                        uint32_t n_nodes, uint32_t refill_at)
 {
-    __shared__ int stack[STACK * kBlock];
-    const uint32_t n = *count;
+    extern __shared__ float4 lds[];
+    int *stack = reinterpret_cast<int *>(lds);                 // STACK * kBlock entries, [entry][lane]
+    float4 *lds_nodes = lds + (STACK * kBlock) / 4;            // 4 * n_nodes lanes      (SCENE_LDS >= 1)
+    float4 *lds_tris = lds_nodes + 4 * static_cast<size_t>(n_nodes);  // 4 * n_triangles (SCENE_LDS == 2)
     const uint32_t tid = threadIdx.x;
+    if (SCENE_LDS >= 1) {
+        for (uint32_t i = tid; i < 4u * n_nodes; i += kBlock) lds_nodes[i] = sc.nodes[i];
+        if (SCENE_LDS >= 2)
+            for (uint32_t i = tid; i < 4u * sc.n_triangles; i += kBlock) lds_tris[i] = sc.triangles[i];
+        __syncthreads();
+    }
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
     unsigned long long my_nodes = 0, my_tris = 0;
-    for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
-        const float4 a = q.p0[i], b = q.p1[i];
-        const f3 o = mk(a.x, a.y, a.z), d = mk(a.w, b.x, b.y);
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-level diagnostics (COUNT only)
 
-        // Reciprocal direction with zero components replaced by +-1e-30 so
-        // that no product below is inf * 0.
-        const float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
-        const float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
-        const float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
-        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-        const float pad = 7.62939453125e-6f * fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), sc.scene_radius));
-        const float mx = pad * fabsf(ix), my = pad * fabsf(iy), mz = pad * fabsf(iz);
-        const float cnx = -(o.x * ix) - mx, cny = -(o.y * iy) - my, cnz = -(o.z * iz) - mz;  // entry planes
-        const float cfx = -(o.x * ix) + mx, cfy = -(o.y * iy) + my, cfz = -(o.z * iz) + mz;  // exit planes
-        const bool negx = ix < 0.f, negy = iy < 0.f, negz = iz < 0.f;
+    for (uint32_t k = blockIdx.x * (kBlock / 64) + (tid >> 6); k < rg.n_regions; k += n_waves) {
+        const uint32_t r = region_of(rg, k);
+        const uint32_t n = rg.counts_in[r];
+        const uint32_t region_base = r << rg.shift;
+        uint32_t next = 0;  // wave-uniform: rays of the region handed out so far
 
+        // per-lane ray state
+        bool active = false, done = false;
+        uint32_t slot = 0;
+        f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
+        float ix = 0.f, iy = 0.f, iz = 0.f, cnx = 0.f, cny = 0.f, cnz = 0.f, cfx = 0.f, cfy = 0.f, cfz = 0.f;
+        bool negx = false, negy = false, negz = false;
         Hit h{__builtin_inff(), -1};
-        int node = 0;
-        int sp = 0;
+        int node = 0, sp = 0;
+
         for (;;) {
-            if (node >= 0) {
-                const float4 *np = sc.nodes + 4 * static_cast<size_t>(node);
-                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                if (COUNT) ++my_nodes;
-                // child 0: lo (n0.x n0.y n0.z) hi (n0.w n1.x n1.y); child 1: lo (n1.z n1.w n2.x) hi (n2.y n2.z n2.w)
-                const float e0x = negx ? n0.w : n0.x, x0x = negx ? n0.x : n0.w;
-                const float e0y = negy ? n1.x : n0.y, x0y = negy ? n0.y : n1.x;
-                const float e0z = negz ? n1.y : n0.z, x0z = negz ? n0.z : n1.y;
-                const float e1x = negx ? n2.y : n1.z, x1x = negx ? n1.z : n2.y;
-                const float e1y = negy ? n2.z : n1.w, x1y = negy ? n1.w : n2.z;
-                const float e1z = negz ? n2.w : n2.x, x1z = negz ? n2.x : n2.w;
-                const float tn0 = fmaxf(fmaxf(fmaf(e0x, ix, cnx), fmaf(e0y, iy, cny)), fmaxf(fmaf(e0z, iz, cnz), 0.f));
-                const float tf0 = fminf(fminf(fmaf(x0x, ix, cfx), fmaf(x0y, iy, cfy)), fminf(fmaf(x0z, iz, cfz), h.t));
-                const float tn1 = fmaxf(fmaxf(fmaf(e1x, ix, cnx), fmaf(e1y, iy, cny)), fmaxf(fmaf(e1z, iz, cnz), 0.f));
-                const float tf1 = fminf(fminf(fmaf(x1x, ix, cfx), fmaf(x1y, iy, cfy)), fminf(fmaf(x1z, iz, cfz), h.t));
-                const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
-                const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                if (hit0 && hit1) {
-                    const bool first0 = tn0 <= tn1;
-                    stack[sp * kBlock + tid] = first0 ? c1 : c0;
-                    ++sp;
-                    node = first0 ? c0 : c1;
-                } else if (hit0) {
-                    node = c0;
-                } else if (hit1) {
-                    node = c1;
+            // ---- hand fresh rays to idle lanes
+            const unsigned long long idle = __ballot(!active);
+            const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
+            if (next < n && (n_idle >= refill_at || n_idle == 64u)) {
+                if (!active) {
+                    const uint32_t my = next + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
+                    if (my < n) {
+                        slot = region_base + my;
+                        const float4 a = q.p0[slot], b = q.p1[slot];
+                        o = mk(a.x, a.y, a.z);
+                        d = mk(a.w, b.x, b.y);
+                        // Reciprocal direction with zero components replaced by +-1e-30
+                        // so that no product below is inf * 0.
+                        const float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+                        const float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+                        const float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+                        ix = 1.0f / dx;
+                        iy = 1.0f / dy;
+                        iz = 1.0f / dz;
+                        const float pad = 7.62939453125e-6f *
+                                          fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), sc.scene_radius));
+                        const float mx = pad * fabsf(ix), my_ = pad * fabsf(iy), mz = pad * fabsf(iz);
+                        cnx = -(o.x * ix) - mx;  // entry planes
+                        cny = -(o.y * iy) - my_;
+                        cnz = -(o.z * iz) - mz;
+                        cfx = -(o.x * ix) + mx;  // exit planes
+                        cfy = -(o.y * iy) + my_;
+                        cfz = -(o.z * iz) + mz;
+                        negx = ix < 0.f;
+                        negy = iy < 0.f;
+                        negz = iz < 0.f;
+                        h.t = __builtin_inff();
+                        h.id = -1;
+                        node = 0;
+                        sp = 0;
+                        done = false;
+                        active = true;
+                    }
+                }
+                if (COUNT) {
+                    dg[6] += 1;
+                    dg[7] += min(n_idle, n - next);
+                }
+                next += n_idle;
+            }
+            if (__ballot(active) == 0ull) break;
+            if (COUNT) {
+                dg[4] += 1;
+                dg[5] += __popcll(__ballot(active));
+            }
+
+            // ---- phase A: inner nodes
+            while (__ballot(active && !done && node >= 0) != 0ull) {
+                if (COUNT) {
+                    dg[0] += 1;
+                    dg[1] += __popcll(__ballot(active && !done && node >= 0));
+                }
+                if (active && !done && node >= 0) {
+                    float4 n0, n1, n2, n3;
+                    if (SCENE_LDS >= 1) {
+                        const float4 *np = lds_nodes + 4 * static_cast<size_t>(node);
+                        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                    } else {
+                        const float4 *np = sc.nodes + 4 * static_cast<size_t>(node);
+                        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                    }
+                    if (COUNT) ++my_nodes;
+                    // child 0: lo (n0.x n0.y n0.z) hi (n0.w n1.x n1.y); child 1: lo (n1.z n1.w n2.x) hi (n2.y n2.z n2.w)
+                    const float e0x = negx ? n0.w : n0.x, x0x = negx ? n0.x : n0.w;
+                    const float e0y = negy ? n1.x : n0.y, x0y = negy ? n0.y : n1.x;
+                    const float e0z = negz ? n1.y : n0.z, x0z = negz ? n0.z : n1.y;
+                    const float e1x = negx ? n2.y : n1.z, x1x = negx ? n1.z : n2.y;
+                    const float e1y = negy ? n2.z : n1.w, x1y = negy ? n1.w : n2.z;
+                    const float e1z = negz ? n2.w : n2.x, x1z = negz ? n2.x : n2.w;
+                    const float tn0 = fmaxf(fmaxf(fmaf(e0x, ix, cnx), fmaf(e0y, iy, cny)), fmaxf(fmaf(e0z, iz, cnz), 0.f));
+                    const float tf0 = fminf(fminf(fmaf(x0x, ix, cfx), fmaf(x0y, iy, cfy)), fminf(fmaf(x0z, iz, cfz), h.t));
+                    const float tn1 = fmaxf(fmaxf(fmaf(e1x, ix, cnx), fmaf(e1y, iy, cny)), fmaxf(fmaf(e1z, iz, cnz), 0.f));
+                    const float tf1 = fminf(fminf(fmaf(x1x, ix, cfx), fmaf(x1y, iy, cfy)), fminf(fmaf(x1z, iz, cfz), h.t));
+                    const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
+                    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                    if (hit0 && hit1) {
+                        const bool first0 = tn0 <= tn1;
+                        stack[sp * kBlock + tid] = first0 ? c1 : c0;
+                        ++sp;
+                        node = first0 ? c0 : c1;
+                    } else if (hit0) {
+                        node = c0;
+                    } else if (hit1) {
+                        node = c1;
+                    } else if (sp == 0) {
+                        done = true;
+                    } else {
+                        --sp;
+                        node = stack[sp * kBlock + tid];
+                    }
+                }
+            }
+
+            // ---- phase B: leaves
+            if (COUNT) {
+                const uint32_t c = (active && !done) ? ((~static_cast<uint32_t>(node)) & 7u) : 0u;
+                uint32_t mx = c;
+                for (int off = 32; off > 0; off >>= 1) mx = max(mx, static_cast<uint32_t>(__shfl_xor(mx, off)));
+                uint32_t sm = c;
+                for (int off = 32; off > 0; off >>= 1) sm += static_cast<uint32_t>(__shfl_xor(sm, off));
+                dg[2] += mx;
+                dg[3] += sm;
+            }
+            if (active && !done) {
+                const uint32_t code = ~static_cast<uint32_t>(node);
+                const uint32_t first = code >> 3, cnt = code & 7u;
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    if (SCENE_LDS >= 2)
+                        test_triangle(lds_tris + 4 * static_cast<size_t>(first + j), o, d, h);
+                    else
+                        test_triangle(sc.triangles + 4 * static_cast<size_t>(first + j), o, d, h);
+                }
+                if (COUNT) my_tris += cnt;
+                if (sp == 0) {
+                    done = true;
                 } else {
-                    if (sp == 0) break;
                     --sp;
                     node = stack[sp * kBlock + tid];
                 }
-            } else {
-                const uint32_t code = ~static_cast<uint32_t>(node);
-                const uint32_t first = code >> 3, cnt = code & 7u;
-                for (uint32_t k = 0; k < cnt; ++k) test_triangle(sc.triangles + 4 * static_cast<size_t>(first + k), o, d, h);
-                if (COUNT) my_tris += cnt;
-                if (sp == 0) break;
-                --sp;
-                node = stack[sp * kBlock + tid];
+            }
+
+            // ---- finished rays: lights, result, lane becomes idle
+            if (active && done) {
+                if (EXACT && !(h.t < __builtin_inff())) {
+                    for (uint32_t j = 0; j < sc.n_triangles; ++j) {
+                        const float4 *tp = sc.triangles + 4 * static_cast<size_t>(j);
+                        const f3 nn = mk(tp[1].w, tp[2].w, tp[3].x);
+                        if (dotm(nn, d) == 0.f) test_triangle(tp, o, d, h);
+                    }
+                }
+                float t = h.t;
+                int code = h.id;
+                test_lights(sc, o, d, t, code);
+                hits[slot] = make_float2(t, __int_as_float(code));
+                active = false;
             }
         }
-        if (EXACT && !(h.t < __builtin_inff())) {
-            for (uint32_t k = 0; k < sc.n_triangles; ++k) {
-                const float4 *tp = sc.triangles + 4 * static_cast<size_t>(k);
-                const f3 n = mk(tp[1].w, tp[2].w, tp[3].x);
-                if (dotm(n, d) == 0.f) test_triangle(tp, o, d, h);
-            }
-        }
-        float t = h.t;
-        int code = h.id;
-        test_lights(sc, o, d, t, code);
-        hits[i] = make_float2(t, __int_as_float(code));
     }
     if (COUNT) {
         atomicAdd(tc.nodes_visited, my_nodes);
         atomicAdd(tc.tris_tested, my_tris);
+        if (tc.diag && (tid & 63u) == 0)
+            for (int j = 0; j < 8; ++j) atomicAdd(tc.diag + j, dg[j]);
     }
 }
 
@@ -572,18 +702,23 @@ __device__ __forceinline__ Material load_material(const SceneView &sc, uint32_t 
 // One bounce for every live path (frag:876-897), then wave64 compaction of
 // the survivors into the next queue: one ballot, one atomic per wave.
 __global__ void __launch_bounds__(kBlock) k_shade(SceneView sc, uint32_t bounce, uint32_t max_depth,
-                                                   const uint32_t *__restrict__ count_in, PathQueue in,
+                                                   Regions rg, PathQueue in,
                                                    const float2 *__restrict__ hits, PathQueue out,
-                                                   uint32_t *__restrict__ count_out, float4 *__restrict__ samples,
+                                                   float4 *__restrict__ samples,
                                                    unsigned long long *__restrict__ nan_counter)
 {
-    const uint32_t n = *count_in;
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-        const uint32_t i = base + threadIdx.x;
+    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    for (uint32_t k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); k < rg.n_regions; k += n_waves) {
+      const uint32_t r = region_of(rg, k);
+      const uint32_t n = rg.counts_in[r];
+      const uint32_t region_base = r << rg.shift;
+      uint32_t out_n = 0;  // wave-uniform: survivors written to this region so far
+      for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+        const uint32_t i = region_base + j0 + lane;
         bool alive = false;
         float4 o0, o1, o2;
-        if (i < n) {
+        if (j0 + lane < n) {
             const float4 a = in.p0[i], b = in.p1[i], c = in.p2[i];
             const float2 hit = hits[i];
             const int code = __float_as_int(hit.y);
@@ -648,21 +783,19 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneView sc, uint32_t bounce,
                 }
             }
         }
+        // wave64 compaction into the wave's own region: ballot + prefix rank, no atomics
         const unsigned long long live = __ballot(alive);
-        if (live != 0ull) {
-            const uint32_t total = static_cast<uint32_t>(__popcll(live));
-            uint32_t wave_base = 0;
-            if (lane == 0) wave_base = atomicAdd(count_out, total);
-            wave_base = __builtin_amdgcn_readfirstlane(wave_base);
-            if (alive) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
-                const uint32_t dst = wave_base + rank;
-                out.p0[dst] = o0;
-                out.p1[dst] = o1;
-                out.p2[dst] = o2;
-            }
+        if (alive) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
+            const uint32_t dst = region_base + out_n + rank;
+            out.p0[dst] = o0;
+            out.p1[dst] = o1;
+            out.p2[dst] = o2;
         }
+        out_n += static_cast<uint32_t>(__popcll(live));
+      }
+      if (lane == 0) rg.counts_out[r] = out_n;
     }
 }
 
@@ -672,13 +805,17 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneView sc, uint32_t bounce,
 // (so the image does not depend on how many iterations share a batch).
 __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ sum,
                                                         uint32_t n_pixels, uint32_t n_iterations,
-                                                        const uint32_t *__restrict__ counts, uint32_t n_counts,
+                                                        const uint32_t *__restrict__ counts, uint32_t n_rows,
+                                                        uint32_t n_regions, uint32_t pitch,
                                                         unsigned long long *__restrict__ segments_total)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    {
+        // segments of this batch = sum of all live counts of all bounces
         unsigned long long s = 0;
-        for (uint32_t k = 0; k < n_counts; ++k) s += counts[k];
-        *segments_total += s;
+        for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_rows * n_regions; k += gridDim.x * kBlock)
+            s += counts[(k / n_regions) * pitch + (k % n_regions)];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if ((threadIdx.x & 63u) == 0 && s != 0) atomicAdd(segments_total, s);
     }
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pixels; p += gridDim.x * kBlock) {
         float4 acc = sum[p];
@@ -712,10 +849,12 @@ __global__ void __launch_bounds__(kBlock) k_unpack_primary(uint32_t n, PathQueue
 }
 
 __global__ void __launch_bounds__(kBlock) k_pack_rays(uint32_t n, const float *__restrict__ origins,
-                                                       const float *__restrict__ dirs, PathQueue q, uint32_t *count_out)
+                                                       const float *__restrict__ dirs, PathQueue q, uint32_t *counts_out,
+                                                       uint32_t region_shift)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = n;
+    const uint32_t region_slots = 1u << region_shift;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        if ((i & (region_slots - 1u)) == 0u) counts_out[i >> region_shift] = min(region_slots, n - i);
         const size_t k = 3 * static_cast<size_t>(i);
         q.p0[i] = make_float4(origins[k], origins[k + 1], origins[k + 2], dirs[k]);
         q.p1[i] = make_float4(dirs[k + 1], dirs[k + 2], 0.f, 0.f);
@@ -780,29 +919,75 @@ __global__ void __launch_bounds__(kBlock) k_sample_surface(uint32_t n, const flo
 
 // ------------------------------------------------------------ launchers
 
+namespace {
+// The region kernels are persistent: the grid is exactly what the device keeps
+// resident (blocks per CU from the occupancy query for this kernel and LDS
+// size), so no block waits for another to retire, and never more waves than
+// there are regions to hand out.
+template <typename K>
+uint32_t resident_grid(K kernel, size_t lds_bytes, LaunchShape g)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    const uint32_t resident = g.n_cus * static_cast<uint32_t>(per_cu);
+    const uint32_t needed = (g.wave_items + (kBlock / 64) - 1) / (kBlock / 64);
+    return needed < resident ? (needed < 1 ? 1 : needed) : resident;
+}
+}  // namespace
+
 void launch_raygen(hipStream_t s, LaunchShape g, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
-                   uint32_t n_iterations, PathQueue out, uint32_t *count_out)
+                   uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift)
 {
     hipLaunchKernelGGL(k_raygen, dim3(g.blocks), dim3(kBlock), 0, s, cam, it_first, it_stride, n_iterations, out,
-                       count_out);
+                       counts_out, region_shift);
 }
 
 void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
-                   const uint32_t *count, PathQueue q, float2 *hits, TraversalCounters tc, bool exact_parallel)
+                   Regions regions, PathQueue q, float2 *hits, TraversalCounters tc, bool exact_parallel,
+                   uint32_t n_nodes, bool scene_in_lds)
 {
+    // Idle lanes that trigger a refill from the wave's region (tunable for experiments).
+    static const uint32_t refill_at = [] {
+        const char *e = std::getenv("PT_REFILL_AT");
+        int v = e ? std::atoi(e) : 16;
+        return static_cast<uint32_t>(v < 1 ? 1 : (v > 64 ? 64 : v));
+    }();
     if (!use_bvh) {
-        hipLaunchKernelGGL(k_extend_scan, dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits);
+        hipLaunchKernelGGL(k_extend_scan, dim3(resident_grid(k_extend_scan, 0, g)), dim3(kBlock), 0, s, scene, regions, q, hits);
         return;
     }
     const bool counting = tc.nodes_visited != nullptr;
-#define PT_LAUNCH_EXTEND(S)                                                                                       \
+    // Dynamic LDS: the per-lane stacks, then as much of the scene as fits in the
+    // 64 KiB a block may ask for without opting in to more.
+    const size_t stack_bytes = static_cast<size_t>(stack_entries <= 16 ? 16 : (stack_entries <= 32 ? 32 : 64)) * kBlock * 4;
+    const size_t node_bytes = static_cast<size_t>(n_nodes) * 64, tri_bytes = static_cast<size_t>(scene.n_triangles) * 64;
+    const size_t budget = 64 * 1024;
+    int lds_mode = 0;
+    if (scene_in_lds && stack_bytes + node_bytes + tri_bytes <= budget)
+        lds_mode = 2;
+    else if (scene_in_lds && stack_bytes + node_bytes <= budget)
+        lds_mode = 1;
+    const size_t lds_bytes = stack_bytes + (lds_mode >= 1 ? node_bytes : 0) + (lds_mode >= 2 ? tri_bytes : 0);
+#define PT_LAUNCH_EXTEND2(S, C, E, L)                                                                              \
+    hipLaunchKernelGGL((k_extend_bvh<S, C, E, L>), dim3(resident_grid(k_extend_bvh<S, C, E, L>, lds_bytes, g)), dim3(kBlock),  \
+                       lds_bytes, s, scene, regions, q, hits, tc, n_nodes, refill_at)
+#define PT_LAUNCH_EXTEND1(S, L)                                                                                    \
     do {                                                                                                          \
         if (exact_parallel)                                                                                       \
-            hipLaunchKernelGGL((k_extend_bvh<S, false, true>), dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits, tc); \
+            PT_LAUNCH_EXTEND2(S, false, true, L);                                                                 \
         else if (counting)                                                                                        \
-            hipLaunchKernelGGL((k_extend_bvh<S, true, false>), dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits, tc); \
+            PT_LAUNCH_EXTEND2(S, true, false, L);                                                                 \
         else                                                                                                      \
-            hipLaunchKernelGGL((k_extend_bvh<S, false, false>), dim3(g.blocks), dim3(kBlock), 0, s, scene, count, q, hits, tc); \
+            PT_LAUNCH_EXTEND2(S, false, false, L);                                                                \
+    } while (0)
+#define PT_LAUNCH_EXTEND(S)                                                                                       \
+    do {                                                                                                          \
+        if (lds_mode == 2)                                                                                        \
+            PT_LAUNCH_EXTEND1(S, 2);                                                                              \
+        else if (lds_mode == 1)                                                                                   \
+            PT_LAUNCH_EXTEND1(S, 1);                                                                              \
+        else                                                                                                      \
+            PT_LAUNCH_EXTEND1(S, 0);                                                                              \
     } while (0)
     if (stack_entries <= 16)
         PT_LAUNCH_EXTEND(16);
@@ -810,23 +995,25 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         PT_LAUNCH_EXTEND(32);
     else
         PT_LAUNCH_EXTEND(64);
+#undef PT_LAUNCH_EXTEND2
+#undef PT_LAUNCH_EXTEND1
 #undef PT_LAUNCH_EXTEND
 }
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t bounce, uint32_t max_depth,
-                  const uint32_t *count_in, PathQueue in, const float2 *hits, PathQueue out, uint32_t *count_out,
-                  float4 *samples, unsigned long long *nan_counter)
+                  Regions regions, PathQueue in, const float2 *hits, PathQueue out, float4 *samples,
+                  unsigned long long *nan_counter)
 {
-    hipLaunchKernelGGL(k_shade, dim3(g.blocks), dim3(kBlock), 0, s, scene, bounce, max_depth, count_in, in, hits, out,
-                       count_out, samples, nan_counter);
+    hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g)), dim3(kBlock), 0, s, scene, bounce, max_depth, regions, in, hits, out,
+                       samples, nan_counter);
 }
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
-                       uint32_t n_iterations, const uint32_t *counts, uint32_t n_counts,
-                       unsigned long long *segments_total)
+                       uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
+                       uint32_t pitch, unsigned long long *segments_total)
 {
     hipLaunchKernelGGL(k_accumulate, dim3(g.blocks), dim3(kBlock), 0, s, samples, sum, n_pixels, n_iterations, counts,
-                       n_counts, segments_total);
+                       n_rows, n_regions, pitch, segments_total);
 }
 
 void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *hits, int32_t *ids,
@@ -836,9 +1023,9 @@ void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q
 }
 
 void launch_pack_rays(hipStream_t s, LaunchShape g, uint32_t n, const float *origins, const float *dirs, PathQueue q,
-                      uint32_t *count_out)
+                      uint32_t *counts_out, uint32_t region_shift)
 {
-    hipLaunchKernelGGL(k_pack_rays, dim3(g.blocks), dim3(kBlock), 0, s, n, origins, dirs, q, count_out);
+    hipLaunchKernelGGL(k_pack_rays, dim3(g.blocks), dim3(kBlock), 0, s, n, origins, dirs, q, counts_out, region_shift);
 }
 
 void launch_tonemap(hipStream_t s, LaunchShape g, const float4 *sum, uint8_t *rgb, uint32_t width, uint32_t height)

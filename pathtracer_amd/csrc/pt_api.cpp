@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -114,8 +115,11 @@ struct pt_renderer {
     float2 *d_hits = nullptr;
     float4 *d_samples = nullptr;
     float4 *d_sum = nullptr;
-    uint32_t *d_counts = nullptr;             // max_depth + 1 live counts of the current batch
-    unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested
+    uint32_t *d_counts = nullptr;             // (max_depth + 1) rows of region_pitch live counts, one row per bounce
+    uint32_t region_pitch = 0;                // regions the queues hold at full capacity
+    uint32_t region_shift = 10;               // log2(slots per region)
+    bool scene_in_lds = true;                 // extend keeps nodes (and triangles) in LDS when they fit
+    unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics
 
     // pt_read_hit_ids / pt_trace_rays report hits at t = +inf on exactly
     // parallel triangles like the reference does (see k_extend_bvh).
@@ -149,6 +153,8 @@ void free_paths(pt_renderer *r)
     if (r->d_hits) (void)hipFree(r->d_hits);
     if (r->d_samples) (void)hipFree(r->d_samples);
     if (r->d_sum) (void)hipFree(r->d_sum);
+    if (r->d_counts) (void)hipFree(r->d_counts);
+    r->d_counts = nullptr;
     r->d_hits = nullptr;
     r->d_samples = nullptr;
     r->d_sum = nullptr;
@@ -176,6 +182,8 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         PT_HIP(hipMalloc(&r->q[b].p1, r->capacity * sizeof(float4)));
         PT_HIP(hipMalloc(&r->q[b].p2, r->capacity * sizeof(float4)));
     }
+    r->region_pitch = static_cast<uint32_t>((r->capacity + (size_t(1) << r->region_shift) - 1) >> r->region_shift);
+    PT_HIP(hipMalloc(&r->d_counts, static_cast<size_t>(r->cfg.max_depth + 1) * r->region_pitch * sizeof(uint32_t)));
     PT_HIP(hipMalloc(&r->d_hits, r->capacity * sizeof(float2)));
     PT_HIP(hipMalloc(&r->d_samples, r->capacity * sizeof(float4)));
     PT_HIP(hipMalloc(&r->d_sum, n_pixels * sizeof(float4)));
@@ -188,17 +196,47 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
     return PT_OK;
 }
 
+uint32_t gcd_u32(uint32_t a, uint32_t b)
+{
+    while (b) {
+        uint32_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+// Region bookkeeping for a launch over n_items queue slots: wave w visits the
+// regions (k * stride) mod n_regions, k = w, w + n_waves, ...; a stride near
+// the golden ratio of n_regions, coprime to it, scatters neighbouring image
+// areas over different waves.
+pt::Regions regions_for(const pt_renderer *r, size_t n_items, uint32_t row_in, int row_out)
+{
+    pt::Regions g;
+    g.shift = r->region_shift;
+    g.n_regions = static_cast<uint32_t>(std::max<size_t>(1, (n_items + (size_t(1) << g.shift) - 1) >> g.shift));
+    uint32_t stride = static_cast<uint32_t>(g.n_regions * 0.6180339887) | 1u;
+    while (gcd_u32(stride, g.n_regions) != 1u) stride += 2u;
+    g.stride = g.n_regions == 1 ? 1u : stride % g.n_regions;
+    if (g.stride == 0) g.stride = 1;
+    g.counts_in = r->d_counts + static_cast<size_t>(row_in) * r->region_pitch;
+    g.counts_out = row_out < 0 ? nullptr : r->d_counts + static_cast<size_t>(row_out) * r->region_pitch;
+    return g;
+}
+
 pt::LaunchShape shape_for(const pt_renderer *r, size_t work_items)
 {
     const size_t blocks_needed = (work_items + 255) / 256;
     const size_t cap = static_cast<size_t>(r->n_cus) * 8;
-    return pt::LaunchShape{static_cast<uint32_t>(std::max<size_t>(1, std::min(blocks_needed, cap)))};
+    const size_t regions = (work_items + (size_t(1) << r->region_shift) - 1) >> r->region_shift;
+    return pt::LaunchShape{static_cast<uint32_t>(std::max<size_t>(1, std::min(blocks_needed, cap))), r->n_cus,
+                           static_cast<uint32_t>(std::max<size_t>(1, regions))};
 }
 
 int reset_accumulation(pt_renderer *r)
 {
     PT_HIP(hipMemsetAsync(r->d_sum, 0, static_cast<size_t>(r->width) * r->height * sizeof(float4), r->stream));
-    PT_HIP(hipMemsetAsync(r->d_counters, 0, 4 * sizeof(unsigned long long), r->stream));
+    PT_HIP(hipMemsetAsync(r->d_counters, 0, 12 * sizeof(unsigned long long), r->stream));
     r->local_iterations = 0;
     r->paths = 0;
     for (int k = 0; k < 4; ++k) {
@@ -249,30 +287,29 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     const size_t n_pixels = static_cast<size_t>(r->width) * r->height;
     const size_t n_paths = n_pixels * kb;
     const uint32_t it_first = static_cast<uint32_t>(r->rank + first_k * r->world);
-    PT_HIP(hipMemsetAsync(r->d_counts, 0, (depth + 1) * sizeof(uint32_t), r->stream));
-    pt::TraversalCounters tc{nullptr, nullptr};
-    if (r->cfg.profile & 2u) tc = pt::TraversalCounters{r->d_counters + 2, r->d_counters + 3};
+    pt::TraversalCounters tc{nullptr, nullptr, nullptr};
+    if (r->cfg.profile & 2u) tc = pt::TraversalCounters{r->d_counters + 2, r->d_counters + 3, r->d_counters + 4};
     const pt::LaunchShape g = shape_for(r, n_paths);
     {
         Timed t(r, 0);
-        pt::launch_raygen(r->stream, g, r->cam, it_first, r->world, kb, r->q[0], r->d_counts);
+        pt::launch_raygen(r->stream, g, r->cam, it_first, r->world, kb, r->q[0], r->d_counts, r->region_shift);
     }
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = r->q[b & 1], &out = r->q[(b + 1) & 1];
         {
             Timed t(r, 1);
-            pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, r->d_counts + b, in, r->d_hits, tc, false);
+            pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, -1), in, r->d_hits, tc, false, r->n_nodes, r->scene_in_lds);
         }
         {
             Timed t(r, 2);
-            pt::launch_shade(r->stream, g, r->view, b, depth, r->d_counts + b, in, r->d_hits, out, r->d_counts + b + 1,
-                             r->d_samples, r->d_counters + 1);
+            pt::launch_shade(r->stream, g, r->view, b, depth, regions_for(r, n_paths, b, static_cast<int>(b) + 1), in, r->d_hits,
+                             out, r->d_samples, r->d_counters + 1);
         }
     }
     {
         Timed t(r, 3);
         pt::launch_accumulate(r->stream, shape_for(r, n_pixels), r->d_samples, r->d_sum, static_cast<uint32_t>(n_pixels), kb,
-                              r->d_counts, depth, r->d_counters);
+                              r->d_counts, depth, regions_for(r, n_paths, 0, -1).n_regions, r->region_pitch, r->d_counters);
     }
     PT_HIP(hipGetLastError());
     if (r->cfg.profile & 1u) {
@@ -605,6 +642,11 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     pt_renderer *r = new pt_renderer();
     r->cfg = cfg;
     r->device = device;
+    if (const char *e = std::getenv("PT_REGION_SHIFT")) {  // tuning experiments only
+        int v = std::atoi(e);
+        if (v >= 6 && v <= 16) r->region_shift = static_cast<uint32_t>(v);
+    }
+    if (const char *e = std::getenv("PT_SCENE_LDS")) r->scene_in_lds = std::atoi(e) != 0;  // tuning experiments only
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         r->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
@@ -618,8 +660,7 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipStreamCreate failed"));
     if ((rc = upload_scene(r, scene)) != PT_OK) return bail(rc);
-    if (hipMalloc(&r->d_counts, (cfg.max_depth + 1) * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&r->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMalloc(&r->d_counters, 12 * sizeof(unsigned long long)) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipMalloc failed"));
     if ((rc = alloc_paths(r, cfg.width, cfg.height)) != PT_OK) return bail(rc);
     r->cam.tan_half_fov = tan_half_fov(cfg.fov_y_degrees);
@@ -646,7 +687,7 @@ void pt_destroy(pt_renderer *r)
     if (r->stream) (void)hipStreamSynchronize(r->stream);
     drain_events(r);
     free_paths(r);
-    void *bufs[] = {r->d_nodes, r->d_tris, r->d_shade, r->d_materials, r->d_lights, r->d_counts, r->d_counters};
+    void *bufs[] = {r->d_nodes, r->d_tris, r->d_shade, r->d_materials, r->d_lights, r->d_counters};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (r->stream) (void)hipStreamDestroy(r->stream);
@@ -766,13 +807,11 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
     const size_t n = static_cast<size_t>(r->width) * r->height;
     int32_t *d_ids = nullptr;
     float *d_t = nullptr, *d_dirs = nullptr;
-    uint32_t *d_count = nullptr;
     hipError_t e = hipSuccess;
     auto cleanup = [&]() {
         if (d_ids) (void)hipFree(d_ids);
         if (d_t) (void)hipFree(d_t);
         if (d_dirs) (void)hipFree(d_dirs);
-        if (d_count) (void)hipFree(d_count);
     };
 #define PT_TRY(expr)                \
     do {                            \
@@ -782,14 +821,13 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
             PT_HIP(e);              \
         }                           \
     } while (0)
-    PT_TRY(hipMalloc(&d_count, sizeof(uint32_t)));
     if (ids) PT_TRY(hipMalloc(&d_ids, n * sizeof(int32_t)));
     if (t) PT_TRY(hipMalloc(&d_t, n * sizeof(float)));
     if (dirs) PT_TRY(hipMalloc(&d_dirs, 3 * n * sizeof(float)));
     const pt::LaunchShape g = shape_for(r, n);
-    pt::launch_raygen(r->stream, g, r->cam, iteration, 1, 1, r->q[0], d_count);
-    pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, d_count, r->q[0], r->d_hits,
-                      pt::TraversalCounters{nullptr, nullptr}, r->exact_readbacks);
+    pt::launch_raygen(r->stream, g, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_shift);
+    pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0], r->d_hits,
+                      pt::TraversalCounters{nullptr, nullptr, nullptr}, r->exact_readbacks, r->n_nodes, r->scene_in_lds);
     pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(n), r->q[0], r->d_hits, d_ids, d_t, d_dirs);
     PT_TRY(hipGetLastError());
     if (ids) PT_TRY(hipMemcpyAsync(ids, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
@@ -809,29 +847,26 @@ int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float 
     const size_t chunk_max = r->capacity;
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
     int32_t *d_ids = nullptr;
-    uint32_t *d_count = nullptr;
     hipError_t e = hipSuccess;
     auto cleanup = [&]() {
         if (d_o) (void)hipFree(d_o);
         if (d_d) (void)hipFree(d_d);
         if (d_t) (void)hipFree(d_t);
         if (d_ids) (void)hipFree(d_ids);
-        if (d_count) (void)hipFree(d_count);
     };
     const size_t m = static_cast<size_t>(std::min<uint64_t>(n, chunk_max));
     PT_TRY(hipMalloc(&d_o, 3 * m * sizeof(float)));
     PT_TRY(hipMalloc(&d_d, 3 * m * sizeof(float)));
     PT_TRY(hipMalloc(&d_t, m * sizeof(float)));
     PT_TRY(hipMalloc(&d_ids, m * sizeof(int32_t)));
-    PT_TRY(hipMalloc(&d_count, sizeof(uint32_t)));
     for (uint64_t off = 0; off < n; off += m) {
         const size_t c = static_cast<size_t>(std::min<uint64_t>(m, n - off));
         PT_TRY(hipMemcpyAsync(d_o, origins + 3 * off, 3 * c * sizeof(float), hipMemcpyHostToDevice, r->stream));
         PT_TRY(hipMemcpyAsync(d_d, dirs + 3 * off, 3 * c * sizeof(float), hipMemcpyHostToDevice, r->stream));
         const pt::LaunchShape g = shape_for(r, c);
-        pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], d_count);
-        pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, d_count, r->q[0], r->d_hits,
-                          pt::TraversalCounters{nullptr, nullptr}, r->exact_readbacks);
+        pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], r->d_counts, r->region_shift);
+        pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, c, 0, -1), r->q[0], r->d_hits,
+                          pt::TraversalCounters{nullptr, nullptr, nullptr}, r->exact_readbacks, r->n_nodes, r->scene_in_lds);
         pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(c), r->q[0], r->d_hits, d_ids, d_t, nullptr);
         PT_TRY(hipGetLastError());
         if (t) PT_TRY(hipMemcpyAsync(t + off, d_t, c * sizeof(float), hipMemcpyDeviceToHost, r->stream));
@@ -986,7 +1021,7 @@ int pt_get_stats(pt_renderer *r, pt_stats *s)
     PT_HIP(hipSetDevice(r->device));
     PT_HIP(hipStreamSynchronize(r->stream));
     drain_events(r);
-    unsigned long long c[4] = {0, 0, 0, 0};
+    unsigned long long c[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     PT_HIP(hipMemcpy(c, r->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     std::memset(s, 0, sizeof(*s));
     s->iterations = r->local_iterations;
@@ -1010,6 +1045,7 @@ int pt_get_stats(pt_renderer *r, pt_stats *s)
     s->launches_shade = r->launches[2];
     s->launches_accumulate = r->launches[3];
     s->sah_cost = r->sah_cost;
+    for (int k = 0; k < 8; ++k) s->extend_diag[k] = c[4 + k];
     return PT_OK;
 }
 
