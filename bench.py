@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 A step is one pass of the wavefront integrator over one batch of synthetic
-work: `--spp-per-step` iterations (samples per pixel) of the scene at
+work: `--spp-per-step` (16) iterations (samples per pixel) of the scene at
 1920x1080, max depth 8, on every rank (weak scaling: rank g of G renders
 iterations g, g+G, ...).  The per-GPU radiance sums are combined by one
 reduce (RCCL when G > 1) at the end of the timed region.  Rank 0 prints ONE
@@ -30,23 +30,25 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (spec)
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (spec, FMA = 2 flops)
 
 # Algorithmic HBM bytes per work item with the queue records this build uses
-# (three 16-byte lanes of path state, an 8-byte hit record, a 16-byte sample):
-EXTEND_BYTES_PER_RAY = 32 + 8          # read origin/direction lanes, write (t, id)
-SHADE_READ_BYTES = 48 + 8              # read path state + hit
-SHADE_WRITE_SURVIVOR = 48              # compacted state of a surviving path
-SAMPLE_BYTES = 16                      # one radiance sample per finished path
+# (three 16-byte lanes of path state, a 16-byte hit record, a 16-byte sample):
+EXTEND_READ_PER_RAY = 32               # origin/direction lanes of every ray
+EXTEND_WRITE_PER_HIT = 16              # hit-list record of a surface hit that will be shaded
+SHADE_READ_PER_HIT = 16 + 48           # hit record + path state
+SHADE_WRITE_PER_SURVIVOR = 48          # compacted state of a surviving path
+RAYGEN_BYTES_PER_PATH = 48 + 16        # path state + zeroed sample slot
+SAMPLE_BYTES = 16                      # one radiance sample per path (read by accumulate)
 
 
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=40)
+    p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--scene", default="Box")
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--depth", type=int, default=8)
-    p.add_argument("--spp-per-step", type=int, default=4)
+    p.add_argument("--spp-per-step", type=int, default=16)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary Veggie.obj measurement")
     return p.parse_args()
@@ -194,12 +196,16 @@ def main():
     out = None
     if rank == 0:
         seg, paths = prof["segments"], prof["paths"]
-        extend_bytes = EXTEND_BYTES_PER_RAY * seg
-        shade_bytes = SHADE_READ_BYTES * seg + SHADE_WRITE_SURVIVOR * (seg - paths) + SAMPLE_BYTES * paths
+        # Every segment beyond a path's first follows a shaded surface hit that survived; a few more hits
+        # are shaded and die (pdf <= 0, zero throughput), so (seg - paths) is a lower bound on shaded hits.
+        shaded = seg - paths
+        extend_bytes = EXTEND_READ_PER_RAY * seg + EXTEND_WRITE_PER_HIT * shaded
+        shade_bytes = SHADE_READ_PER_HIT * shaded + SHADE_WRITE_PER_SURVIVOR * shaded
         kernels = {
             "extend": {"ms_total": prof["ms_extend"], "launches": prof["launches_extend"], "algorithmic_bytes": extend_bytes},
             "shade": {"ms_total": prof["ms_shade"], "launches": prof["launches_shade"], "algorithmic_bytes": shade_bytes},
-            "raygen": {"ms_total": prof["ms_raygen"], "launches": prof["launches_raygen"], "algorithmic_bytes": 48 * paths},
+            "raygen": {"ms_total": prof["ms_raygen"], "launches": prof["launches_raygen"],
+                       "algorithmic_bytes": RAYGEN_BYTES_PER_PATH * paths},
             "accumulate": {"ms_total": prof["ms_accumulate"], "launches": prof["launches_accumulate"],
                            "algorithmic_bytes": 16 * paths + 32 * n_pixels * prof["launches_accumulate"]},
         }

@@ -16,7 +16,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpathtracer_amd.so")
+# PT_AMD_LIB selects another build of the same library (kernel tuning experiments).
+LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(_HERE, "libpathtracer_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

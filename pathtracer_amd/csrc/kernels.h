@@ -66,26 +66,40 @@ struct LaunchShape {
 
 // counts_out: n_regions live counts of bounce 0.
 void launch_raygen(hipStream_t s, LaunchShape g, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
-                   uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift);
+                   uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift,
+                   float4 *samples /* zeroed per path when not null */);
+
+// Where extend puts its results.
+//  render = false: hit_list is written as a float2 array, results[slot] = (t, hit code), for every ray
+//                  (readbacks); exact_parallel also reports the reference's hits at t = +inf on triangles
+//                  whose plane the ray is exactly parallel to.
+//  render = true : rays that reach a light write samples[path slot]; rays that escape (or hit a surface on
+//                  the last allowed segment) add nothing; other surface hits are appended per region to
+//                  hit_list as (t, triangle, slot in region, -) and regions.counts_out receives their number.
+struct ExtendOutput {
+    float4 *hit_list;
+    float4 *samples;
+    unsigned long long *nan_counter;
+    bool render;
+    bool last_segment;
+    bool exact_parallel;
+};
 
 // stack_entries selects the traversal-stack instantiation (16, 32 or 64).
-// exact_parallel: also report the reference's hits at t = +inf on triangles
-// whose plane the ray is exactly parallel to (readbacks only; such a hit
-// contributes nothing to an image).
 void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
-                   Regions regions, PathQueue q, float2 *hits, TraversalCounters tc, bool exact_parallel,
-                   uint32_t n_nodes, bool scene_in_lds);
+                   Regions regions, PathQueue q, const ExtendOutput &out, TraversalCounters tc, uint32_t n_nodes,
+                   bool scene_in_lds);
 
-void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t bounce, uint32_t max_depth,
-                  Regions regions, PathQueue in, const float2 *hits, PathQueue out, float4 *samples,
-                  unsigned long long *nan_counter);
+// regions.counts_in = hits per region, regions.counts_out = surviving paths per region.
+void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
+                  const float4 *hit_list, PathQueue out);
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
                        uint32_t pitch, unsigned long long *segments_total);
 
 // hits -> int32 hit codes / t / directions in pixel order for one iteration.
-void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *hits, int32_t *ids,
+void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *results, int32_t *ids,
                            float *t, float *dirs);
 
 void launch_pack_rays(hipStream_t s, LaunchShape g, uint32_t n, const float *origins, const float *dirs, PathQueue q,

@@ -22,6 +22,16 @@ namespace pt {
 namespace {
 
 constexpr int kBlock = 256;
+// Minimum waves per SIMD the register allocator must leave room for (second
+// argument of __launch_bounds__).
+#ifndef PT_EXTEND_WAVES
+#define PT_EXTEND_WAVES 1
+#endif
+// Measured on MI355X (Box / Veggie at 1080p): shade is fastest at 5 waves per SIMD
+// (96 VGPRs, 24 bytes of scratch); extend is fastest with its natural 74 VGPRs.
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 5
+#endif
 constexpr float kPi = 3.14159265358979323f;     // frag:3
 constexpr float kInvPi = 0.31830988618379067f;  // frag:4
 
@@ -60,7 +70,7 @@ __device__ __forceinline__ float rng_next(uint32_t &sx, uint32_t &sy)
 // frag:866 + frag:306-320.  Path slot i = k * (W*H) + pixel, pixel = y*W + x.
 __global__ void __launch_bounds__(kBlock) k_raygen(DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
                                                     uint32_t n_iterations, PathQueue out, uint32_t *counts_out,
-                                                    uint32_t region_shift)
+                                                    uint32_t region_shift, float4 *__restrict__ samples)
 {
     const uint32_t region_slots = 1u << region_shift;
     const uint32_t n_pixels = cam.width * cam.height;
@@ -91,6 +101,8 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceCamera cam, uint32_t it
         out.p0[i] = make_float4(eye.x, eye.y, eye.z, d.x);
         out.p1[i] = make_float4(d.y, d.z, __uint_as_float(sx), __uint_as_float(sy));
         out.p2[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(i));
+        // Only a path that reaches a light writes its sample; everything else adds zero.
+        if (samples) samples[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((i & (region_slots - 1u)) == 0u) counts_out[i >> region_shift] = min(region_slots, total - i);
     }
 }
@@ -155,25 +167,58 @@ __device__ __forceinline__ void test_lights(const SceneView &sc, f3 o, f3 d, flo
 }
 
 // Linear scan in the reference's triangle order (frag:391-416).
+template <bool RENDER>
 __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg, PathQueue q,
-                                                         float2 *__restrict__ hits)
+                                                         float4 *__restrict__ hit_list, float4 *__restrict__ samples,
+                                                         unsigned long long *__restrict__ nan_counter, uint32_t last_segment)
 {
+    float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
     for (uint32_t k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); k < rg.n_regions; k += n_waves) {
       const uint32_t r = region_of(rg, k);
       const uint32_t n = rg.counts_in[r];
-      for (uint32_t j = lane; j < n; j += 64u) {
-        const uint32_t i = (r << rg.shift) + j;
-        const float4 a = q.p0[i], b = q.p1[i];
-        const f3 o = mk(a.x, a.y, a.z), d = mk(a.w, b.x, b.y);
-        Hit h{__builtin_inff(), -1};
-        for (uint32_t t = 0; t < sc.n_triangles; ++t) test_triangle(sc.triangles + 4 * static_cast<size_t>(t), o, d, h);
-        float t = h.t;
-        int code = h.id;
-        test_lights(sc, o, d, t, code);
-        hits[i] = make_float2(t, __int_as_float(code));
+      const uint32_t region_base = r << rg.shift;
+      uint32_t hit_n = 0;
+      for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+        bool append = false;
+        float t = 0.f;
+        int code = -1;
+        const uint32_t i = region_base + j0 + lane;
+        if (j0 + lane < n) {
+            const float4 a = q.p0[i], b = q.p1[i];
+            const f3 o = mk(a.x, a.y, a.z), d = mk(a.w, b.x, b.y);
+            Hit h{__builtin_inff(), -1};
+            for (uint32_t tri = 0; tri < sc.n_triangles; ++tri) test_triangle(sc.triangles + 4 * static_cast<size_t>(tri), o, d, h);
+            t = h.t;
+            code = h.id;
+            test_lights(sc, o, d, t, code);
+            if (!RENDER) {
+                results[i] = make_float2(t, __int_as_float(code));
+            } else if (code <= -2) {
+                const float4 c = q.p2[i];
+                const float *rad = sc.lights[-(code + 2)].radiance;
+                f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
+                if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) {
+                    L = mk(0.f, 0.f, 0.f);
+                    atomicAdd(nan_counter, 1ull);
+                }
+                samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, 1.f);
+            } else {
+                append = code >= 0 && last_segment == 0u;
+            }
+        }
+        if (RENDER) {
+            const unsigned long long app = __ballot(append);
+            if (append) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(app >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(app), 0u));
+                hit_list[region_base + hit_n + rank] = make_float4(t, __int_as_float(code), __uint_as_float(j0 + lane), 0.f);
+            }
+            hit_n += static_cast<uint32_t>(__popcll(app));
+        }
       }
+      if (RENDER && lane == 0) rg.counts_out[r] = hit_n;
     }
 }
 
@@ -208,11 +253,20 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 // SCENE_LDS: 0 = nodes and triangles are read from global memory (L1/L2);
 // 1 = the block keeps a copy of the node array in LDS; 2 = nodes and
 // triangles.  The host picks the largest variant that fits beside the stacks.
-template <int STACK, bool COUNT, bool EXACT, int SCENE_LDS>
-__global__ void __launch_bounds__(kBlock) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
-                                                        float2 *__restrict__ hits, TraversalCounters tc,
-                                                        uint32_t n_nodes, uint32_t refill_at)
+//
+// RENDER = false (readbacks): every ray's (t, hit code) goes to results[slot].
+// RENDER = true (the render loop): the kernel also ends the paths that end
+// here -- a ray that reaches a light writes its sample (frag:878-882), a ray
+// that escapes or sits on the last allowed segment adds nothing -- and appends
+// the remaining surface hits, compacted per region with ballot + prefix rank,
+// to the hit list the shade kernel consumes: (t, triangle, slot in region).
+template <int STACK, bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER>
+__global__ void __launch_bounds__(kBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
+                                                        float4 *__restrict__ hit_list, float4 *__restrict__ samples,
+                                                        unsigned long long *__restrict__ nan_counter, uint32_t last_segment,
+                                                        TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at)
 {
+    float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     extern __shared__ float4 lds[];
     int *stack = reinterpret_cast<int *>(lds);                 // STACK * kBlock entries, [entry][lane]
     float4 *lds_nodes = lds + (STACK * kBlock) / 4;            // 4 * n_nodes lanes      (SCENE_LDS >= 1)
@@ -232,7 +286,8 @@ __global__ void __launch_bounds__(kBlock) k_extend_bvh(SceneView sc, Regions rg,
         const uint32_t r = region_of(rg, k);
         const uint32_t n = rg.counts_in[r];
         const uint32_t region_base = r << rg.shift;
-        uint32_t next = 0;  // wave-uniform: rays of the region handed out so far
+        uint32_t next = 0;   // wave-uniform: rays of the region handed out so far
+        uint32_t hit_n = 0;  // wave-uniform: surface hits appended to the region's hit list
 
         // per-lane ray state
         bool active = false, done = false;
@@ -372,6 +427,9 @@ __global__ void __launch_bounds__(kBlock) k_extend_bvh(SceneView sc, Regions rg,
             }
 
             // ---- finished rays: lights, result, lane becomes idle
+            bool append = false;
+            float hit_t = 0.f;
+            int hit_code = -1;
             if (active && done) {
                 if (EXACT && !(h.t < __builtin_inff())) {
                     for (uint32_t j = 0; j < sc.n_triangles; ++j) {
@@ -380,13 +438,38 @@ __global__ void __launch_bounds__(kBlock) k_extend_bvh(SceneView sc, Regions rg,
                         if (dotm(nn, d) == 0.f) test_triangle(tp, o, d, h);
                     }
                 }
-                float t = h.t;
-                int code = h.id;
-                test_lights(sc, o, d, t, code);
-                hits[slot] = make_float2(t, __int_as_float(code));
+                hit_t = h.t;
+                hit_code = h.id;
+                test_lights(sc, o, d, hit_t, hit_code);
+                if (!RENDER) {
+                    results[slot] = make_float2(hit_t, __int_as_float(hit_code));
+                } else if (hit_code <= -2) {
+                    // passCol = attenuation * intensity (frag:878-882, :901)
+                    const float4 c = q.p2[slot];
+                    const float *rad = sc.lights[-(hit_code + 2)].radiance;
+                    f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
+                    if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) {
+                        L = mk(0.f, 0.f, 0.f);
+                        atomicAdd(nan_counter, 1ull);
+                    }
+                    samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, 1.f);
+                } else {
+                    append = hit_code >= 0 && last_segment == 0u;
+                }
                 active = false;
             }
+            if (RENDER) {
+                const unsigned long long app = __ballot(append);
+                if (append) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(app >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(app), 0u));
+                    hit_list[region_base + hit_n + rank] =
+                        make_float4(hit_t, __int_as_float(hit_code), __uint_as_float(slot - region_base), 0.f);
+                }
+                hit_n += static_cast<uint32_t>(__popcll(app));
+            }
         }
+        if (RENDER && (tid & 63u) == 0) rg.counts_out[r] = hit_n;
     }
     if (COUNT) {
         atomicAdd(tc.nodes_visited, my_nodes);
@@ -699,13 +782,13 @@ __device__ __forceinline__ Material load_material(const SceneView &sc, uint32_t 
     return m;
 }
 
-// One bounce for every live path (frag:876-897), then wave64 compaction of
-// the survivors into the next queue: one ballot, one atomic per wave.
-__global__ void __launch_bounds__(kBlock) k_shade(SceneView sc, uint32_t bounce, uint32_t max_depth,
-                                                   Regions rg, PathQueue in,
-                                                   const float2 *__restrict__ hits, PathQueue out,
-                                                   float4 *__restrict__ samples,
-                                                   unsigned long long *__restrict__ nan_counter)
+// One bounce for every surface hit of the hit list (frag:884-897), then wave64
+// compaction of the surviving paths into the wave's own region of the next
+// queue: one ballot + prefix rank per 64 hits, no atomics.  A path that dies
+// here (pdf <= 0, a lobe that returned without a direction, zero throughput)
+// simply is not written: its sample slot already holds zero.
+__global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, Regions rg, PathQueue in,
+                                                   const float4 *__restrict__ hit_list, PathQueue out)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
@@ -715,32 +798,19 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneView sc, uint32_t bounce,
       const uint32_t region_base = r << rg.shift;
       uint32_t out_n = 0;  // wave-uniform: survivors written to this region so far
       for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
-        const uint32_t i = region_base + j0 + lane;
         bool alive = false;
         float4 o0, o1, o2;
         if (j0 + lane < n) {
+            const float4 rec = hit_list[region_base + j0 + lane];
+            const uint32_t i = region_base + __float_as_uint(rec.z);
             const float4 a = in.p0[i], b = in.p1[i], c = in.p2[i];
-            const float2 hit = hits[i];
-            const int code = __float_as_int(hit.y);
-            const uint32_t slot = __float_as_uint(c.w);
+            const int code = __float_as_int(rec.y);
             const f3 thr = mk(c.x, c.y, c.z);
-            if (code <= -2) {
-                // frag:878-882: radiance arrives; passCol = attenuation * intensity.
-                const float *rad = sc.lights[-(code + 2)].radiance;
-                f3 L = mk(thr.x * rad[0], thr.y * rad[1], thr.z * rad[2]);
-                if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) {
-                    L = mk(0.f, 0.f, 0.f);
-                    atomicAdd(nan_counter, 1ull);
-                }
-                samples[slot] = make_float4(L.x, L.y, L.z, 1.f);
-            } else if (code == -1 || bounce + 1u >= max_depth) {
-                // Escaped, or no segment left in which a light could be reached.
-                samples[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
-            } else {
+            {
                 const f3 o = mk(a.x, a.y, a.z), d = mk(a.w, b.x, b.y);
                 uint32_t sx = __float_as_uint(b.z), sy = __float_as_uint(b.w);
                 // frag:434-453
-                const float t = hit.x;
+                const float t = rec.x;
                 const f3 p = mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
                 const float4 *sp = sc.shade + 5 * static_cast<size_t>(code);
                 const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
@@ -772,9 +842,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneView sc, uint32_t bounce,
                         if (att.x == 0.f && att.y == 0.f && att.z == 0.f) dead = true;
                     }
                 }
-                if (dead) {
-                    samples[slot] = make_float4(0.f, 0.f, 0.f, 1.f);
-                } else {
+                if (!dead) {
                     alive = true;
                     const f3 no = mk(p.x + r.wi.x * 0.0001f, p.y + r.wi.y * 0.0001f, p.z + r.wi.z * 0.0001f);
                     o0 = make_float4(no.x, no.y, no.z, r.wi.x);
@@ -783,7 +851,6 @@ __global__ void __launch_bounds__(kBlock) k_shade(SceneView sc, uint32_t bounce,
                 }
             }
         }
-        // wave64 compaction into the wave's own region: ballot + prefix rank, no atomics
         const unsigned long long live = __ballot(alive);
         if (alive) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
@@ -936,15 +1003,15 @@ uint32_t resident_grid(K kernel, size_t lds_bytes, LaunchShape g)
 }  // namespace
 
 void launch_raygen(hipStream_t s, LaunchShape g, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
-                   uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift)
+                   uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift, float4 *samples)
 {
     hipLaunchKernelGGL(k_raygen, dim3(g.blocks), dim3(kBlock), 0, s, cam, it_first, it_stride, n_iterations, out,
-                       counts_out, region_shift);
+                       counts_out, region_shift, samples);
 }
 
 void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
-                   Regions regions, PathQueue q, float2 *hits, TraversalCounters tc, bool exact_parallel,
-                   uint32_t n_nodes, bool scene_in_lds)
+                   Regions regions, PathQueue q, const ExtendOutput &out, TraversalCounters tc, uint32_t n_nodes,
+                   bool scene_in_lds)
 {
     // Idle lanes that trigger a refill from the wave's region (tunable for experiments).
     static const uint32_t refill_at = [] {
@@ -952,8 +1019,16 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         int v = e ? std::atoi(e) : 16;
         return static_cast<uint32_t>(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
+    const bool render = out.render;
+    const bool exact_parallel = out.exact_parallel && !render;
+    const uint32_t last = out.last_segment ? 1u : 0u;
     if (!use_bvh) {
-        hipLaunchKernelGGL(k_extend_scan, dim3(resident_grid(k_extend_scan, 0, g)), dim3(kBlock), 0, s, scene, regions, q, hits);
+        if (render)
+            hipLaunchKernelGGL(k_extend_scan<true>, dim3(resident_grid(k_extend_scan<true>, 0, g)), dim3(kBlock), 0, s, scene,
+                               regions, q, out.hit_list, out.samples, out.nan_counter, last);
+        else
+            hipLaunchKernelGGL(k_extend_scan<false>, dim3(resident_grid(k_extend_scan<false>, 0, g)), dim3(kBlock), 0, s, scene,
+                               regions, q, out.hit_list, out.samples, out.nan_counter, last);
         return;
     }
     const bool counting = tc.nodes_visited != nullptr;
@@ -968,17 +1043,20 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     else if (scene_in_lds && stack_bytes + node_bytes <= budget)
         lds_mode = 1;
     const size_t lds_bytes = stack_bytes + (lds_mode >= 1 ? node_bytes : 0) + (lds_mode >= 2 ? tri_bytes : 0);
-#define PT_LAUNCH_EXTEND2(S, C, E, L)                                                                              \
-    hipLaunchKernelGGL((k_extend_bvh<S, C, E, L>), dim3(resident_grid(k_extend_bvh<S, C, E, L>, lds_bytes, g)), dim3(kBlock),  \
-                       lds_bytes, s, scene, regions, q, hits, tc, n_nodes, refill_at)
+#define PT_LAUNCH_EXTEND2(S, C, E, L, R)                                                                           \
+    hipLaunchKernelGGL((k_extend_bvh<S, C, E, L, R>), dim3(resident_grid(k_extend_bvh<S, C, E, L, R>, lds_bytes, g)),  \
+                       dim3(kBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples, out.nan_counter, last, \
+                       tc, n_nodes, refill_at)
 #define PT_LAUNCH_EXTEND1(S, L)                                                                                    \
     do {                                                                                                          \
         if (exact_parallel)                                                                                       \
-            PT_LAUNCH_EXTEND2(S, false, true, L);                                                                 \
+            PT_LAUNCH_EXTEND2(S, false, true, L, false);                                                          \
+        else if (!render)                                                                                         \
+            PT_LAUNCH_EXTEND2(S, false, false, L, false);                                                         \
         else if (counting)                                                                                        \
-            PT_LAUNCH_EXTEND2(S, true, false, L);                                                                 \
+            PT_LAUNCH_EXTEND2(S, true, false, L, true);                                                           \
         else                                                                                                      \
-            PT_LAUNCH_EXTEND2(S, false, false, L);                                                                \
+            PT_LAUNCH_EXTEND2(S, false, false, L, true);                                                          \
     } while (0)
 #define PT_LAUNCH_EXTEND(S)                                                                                       \
     do {                                                                                                          \
@@ -1000,12 +1078,10 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
 #undef PT_LAUNCH_EXTEND
 }
 
-void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t bounce, uint32_t max_depth,
-                  Regions regions, PathQueue in, const float2 *hits, PathQueue out, float4 *samples,
-                  unsigned long long *nan_counter)
+void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
+                  const float4 *hit_list, PathQueue out)
 {
-    hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g)), dim3(kBlock), 0, s, scene, bounce, max_depth, regions, in, hits, out,
-                       samples, nan_counter);
+    hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g)), dim3(kBlock), 0, s, scene, regions, in, hit_list, out);
 }
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,

@@ -112,7 +112,7 @@ struct pt_renderer {
     uint32_t width = 0, height = 0, batch_iterations = 1;
     size_t capacity = 0;
     pt::PathQueue q[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    float2 *d_hits = nullptr;
+    float4 *d_hits = nullptr;                 // hit list of the render loop; (t, code) results of the readbacks
     float4 *d_samples = nullptr;
     float4 *d_sum = nullptr;
     uint32_t *d_counts = nullptr;             // (max_depth + 1) rows of region_pitch live counts, one row per bounce
@@ -183,8 +183,9 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         PT_HIP(hipMalloc(&r->q[b].p2, r->capacity * sizeof(float4)));
     }
     r->region_pitch = static_cast<uint32_t>((r->capacity + (size_t(1) << r->region_shift) - 1) >> r->region_shift);
-    PT_HIP(hipMalloc(&r->d_counts, static_cast<size_t>(r->cfg.max_depth + 1) * r->region_pitch * sizeof(uint32_t)));
-    PT_HIP(hipMalloc(&r->d_hits, r->capacity * sizeof(float2)));
+    // rows 0..depth: live rays per region and bounce; rows depth+1..2*depth: surface hits per region and bounce
+    PT_HIP(hipMalloc(&r->d_counts, static_cast<size_t>(2 * r->cfg.max_depth + 1) * r->region_pitch * sizeof(uint32_t)));
+    PT_HIP(hipMalloc(&r->d_hits, r->capacity * sizeof(float4)));
     PT_HIP(hipMalloc(&r->d_samples, r->capacity * sizeof(float4)));
     PT_HIP(hipMalloc(&r->d_sum, n_pixels * sizeof(float4)));
     PT_HIP(hipMemsetAsync(r->d_sum, 0, n_pixels * sizeof(float4), r->stream));
@@ -292,18 +293,22 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     const pt::LaunchShape g = shape_for(r, n_paths);
     {
         Timed t(r, 0);
-        pt::launch_raygen(r->stream, g, r->cam, it_first, r->world, kb, r->q[0], r->d_counts, r->region_shift);
+        pt::launch_raygen(r->stream, g, r->cam, it_first, r->world, kb, r->q[0], r->d_counts, r->region_shift, r->d_samples);
     }
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = r->q[b & 1], &out = r->q[(b + 1) & 1];
+        const bool last = (b + 1 == depth);
+        const int hit_row = static_cast<int>(depth + 1 + b);
         {
             Timed t(r, 1);
-            pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, -1), in, r->d_hits, tc, false, r->n_nodes, r->scene_in_lds);
+            pt::ExtendOutput eo{r->d_hits, r->d_samples, r->d_counters + 1, true, last, false};
+            pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, hit_row), in,
+                              eo, tc, r->n_nodes, r->scene_in_lds);
         }
-        {
+        if (!last) {
             Timed t(r, 2);
-            pt::launch_shade(r->stream, g, r->view, b, depth, regions_for(r, n_paths, b, static_cast<int>(b) + 1), in, r->d_hits,
-                             out, r->d_samples, r->d_counters + 1);
+            pt::launch_shade(r->stream, g, r->view, regions_for(r, n_paths, static_cast<uint32_t>(hit_row), static_cast<int>(b) + 1), in,
+                             r->d_hits, out);
         }
     }
     {
@@ -825,10 +830,12 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
     if (t) PT_TRY(hipMalloc(&d_t, n * sizeof(float)));
     if (dirs) PT_TRY(hipMalloc(&d_dirs, 3 * n * sizeof(float)));
     const pt::LaunchShape g = shape_for(r, n);
-    pt::launch_raygen(r->stream, g, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_shift);
-    pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0], r->d_hits,
-                      pt::TraversalCounters{nullptr, nullptr, nullptr}, r->exact_readbacks, r->n_nodes, r->scene_in_lds);
-    pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(n), r->q[0], r->d_hits, d_ids, d_t, d_dirs);
+    pt::launch_raygen(r->stream, g, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_shift, nullptr);
+    pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0],
+                      pt::ExtendOutput{r->d_hits, nullptr, nullptr, false, false, r->exact_readbacks},
+                      pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
+    pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(n), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids, d_t,
+                              d_dirs);
     PT_TRY(hipGetLastError());
     if (ids) PT_TRY(hipMemcpyAsync(ids, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
     if (t) PT_TRY(hipMemcpyAsync(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
@@ -865,9 +872,11 @@ int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float 
         PT_TRY(hipMemcpyAsync(d_d, dirs + 3 * off, 3 * c * sizeof(float), hipMemcpyHostToDevice, r->stream));
         const pt::LaunchShape g = shape_for(r, c);
         pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], r->d_counts, r->region_shift);
-        pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, c, 0, -1), r->q[0], r->d_hits,
-                          pt::TraversalCounters{nullptr, nullptr, nullptr}, r->exact_readbacks, r->n_nodes, r->scene_in_lds);
-        pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(c), r->q[0], r->d_hits, d_ids, d_t, nullptr);
+        pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, c, 0, -1), r->q[0],
+                          pt::ExtendOutput{r->d_hits, nullptr, nullptr, false, false, r->exact_readbacks},
+                          pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
+        pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(c), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids,
+                                  d_t, nullptr);
         PT_TRY(hipGetLastError());
         if (t) PT_TRY(hipMemcpyAsync(t + off, d_t, c * sizeof(float), hipMemcpyDeviceToHost, r->stream));
         if (ids) PT_TRY(hipMemcpyAsync(ids + off, d_ids, c * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
