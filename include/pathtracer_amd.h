@@ -85,6 +85,9 @@ typedef struct {
      * iterations, lane-triangle tests, rounds, lanes holding a ray per round,
      * refills, rays handed out. */
     uint64_t extend_diag[8];
+    /* Lane occupancy of the shade kernel after compaction: surface hits shaded and
+     * the 64-lane batches they were processed in (fill = hits / (64 * batches)). */
+    uint64_t hits_shaded, shade_batches;
 } pt_stats;
 
 const char *pt_last_error(void);

@@ -106,6 +106,8 @@ class Stats(C.Structure):
         ("launches_accumulate", C.c_uint64),
         ("sah_cost", C.c_double),
         ("extend_diag", C.c_uint64 * 8),
+        ("hits_shaded", C.c_uint64),
+        ("shade_batches", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:

@@ -27,9 +27,14 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode is one 64-byte record");
 //   t1 = (v1.x, v1.y, v1.z, n.x)     n  = normalize(cross(v1-v0, v2-v0))
 //   t2 = (v2.x, v2.y, v2.z, n.y)
 //   t3 = (n.z, original triangle index bits, 0, 0)
+// The renderer sets kHitClassBit in the uploaded index of triangles whose
+// material is not purely diffuse; the kernels mask it off wherever the index
+// is compared or reported.
 // n and d0 are evaluated exactly as the reference shader evaluates them per
 // ray (pathtracer.frag.glsl:399-404): same operations, same order, no
 // contraction, so hoisting them out of the ray loop changes no bit.
+constexpr uint32_t kHitClassBit = 1u << 30;
+
 struct BvhTriangle {
     float v0[3], d0;
     float v1[3], nx;

@@ -96,7 +96,8 @@ void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions 
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
-                       uint32_t pitch, unsigned long long *segments_total);
+                       uint32_t pitch, unsigned long long *segments_total,
+                       unsigned long long *shade_totals /* [0] surface hits shaded, [1] 64-lane batches formed */);
 
 // hits -> int32 hit codes / t / directions in pixel order for one iteration.
 void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *results, int32_t *ids,

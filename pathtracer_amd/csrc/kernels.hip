@@ -22,6 +22,19 @@ namespace pt {
 namespace {
 
 constexpr int kBlock = 256;
+// Experiment knobs of the traversal kernel: threads per block (the block shares
+// one LDS copy of the scene) and the type of a stack entry.
+#ifndef PT_EXT_BLOCK
+#define PT_EXT_BLOCK 256
+#endif
+#ifndef PT_STACK_T
+#define PT_STACK_T int
+#endif
+#ifndef PT_LDS_BUDGET
+#define PT_LDS_BUDGET (64 * 1024)
+#endif
+constexpr int kExtBlock = PT_EXT_BLOCK;
+using StackT = PT_STACK_T;
 // Minimum waves per SIMD the register allocator must leave room for (second
 // argument of __launch_bounds__).
 #ifndef PT_EXTEND_WAVES
@@ -118,8 +131,10 @@ __device__ __forceinline__ uint32_t region_of(const Regions &rg, uint32_t k)
 
 struct Hit {
     float t;
-    int id;  // original triangle index, -1 none
+    int id;  // original triangle index (| kClassBit for a surface that is not purely diffuse), -1 none
 };
+constexpr int kClassBit = 1 << 30;
+constexpr int kIdMask = kClassBit - 1;
 
 // frag:393-415 with n and dot(n,v0) hoisted (same operations, same bits).
 // Among equal t the larger original index wins, which is what visiting the
@@ -135,8 +150,8 @@ __device__ __forceinline__ void test_triangle(const float4 *__restrict__ tp, f3 
     if (dotm(crossm(v1 - v0, Q - v0), n) < 0.f) return;
     if (dotm(crossm(v2 - v1, Q - v1), n) < 0.f) return;
     if (dotm(crossm(v0 - v2, Q - v2), n) < 0.f) return;
-    const int orig = __float_as_int(t3.y);
-    if (st == h.t && orig < h.id) return;
+    const int orig = __float_as_int(t3.y);  // index | class bit
+    if (st == h.t && (orig & kIdMask) < (h.id < 0 ? h.id : (h.id & kIdMask))) return;
     h.t = st;
     h.id = orig;
 }
@@ -166,6 +181,25 @@ __device__ __forceinline__ void test_lights(const SceneView &sc, f3 o, f3 d, flo
     }
 }
 
+// The hit list of a region has two ends: purely diffuse surfaces are appended
+// upwards from the region's first slot, all other surfaces downwards from its
+// last, so that the shade kernel's waves mostly see one kind of material.
+// Ballot + prefix rank per end; n0 / n1 are the wave-uniform counts so far.
+__device__ __forceinline__ void append_hit(float4 *__restrict__ hit_list, uint32_t region_base, uint32_t shift, bool append,
+                                           bool other, float4 rec, uint32_t &n0, uint32_t &n1)
+{
+    const unsigned long long m0 = __ballot(append && !other), m1 = __ballot(append && other);
+    if (append) {
+        const unsigned long long m = other ? m1 : m0;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+        const uint32_t at = other ? ((1u << shift) - 1u - (n1 + rank)) : (n0 + rank);
+        hit_list[region_base + at] = rec;
+    }
+    n0 += static_cast<uint32_t>(__popcll(m0));
+    n1 += static_cast<uint32_t>(__popcll(m1));
+}
+
 // Linear scan in the reference's triangle order (frag:391-416).
 template <bool RENDER>
 __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg, PathQueue q,
@@ -179,11 +213,12 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
       const uint32_t r = region_of(rg, k);
       const uint32_t n = rg.counts_in[r];
       const uint32_t region_base = r << rg.shift;
-      uint32_t hit_n = 0;
+      uint32_t hit_n0 = 0, hit_n1 = 0;
       for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
         bool append = false;
         float t = 0.f;
         int code = -1;
+        bool other = false;
         const uint32_t i = region_base + j0 + lane;
         if (j0 + lane < n) {
             const float4 a = q.p0[i], b = q.p1[i];
@@ -191,7 +226,8 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
             Hit h{__builtin_inff(), -1};
             for (uint32_t tri = 0; tri < sc.n_triangles; ++tri) test_triangle(sc.triangles + 4 * static_cast<size_t>(tri), o, d, h);
             t = h.t;
-            code = h.id;
+            code = h.id < 0 ? h.id : (h.id & kIdMask);
+            other = h.id >= 0 && (h.id & kClassBit) != 0;
             test_lights(sc, o, d, t, code);
             if (!RENDER) {
                 results[i] = make_float2(t, __int_as_float(code));
@@ -208,17 +244,11 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
                 append = code >= 0 && last_segment == 0u;
             }
         }
-        if (RENDER) {
-            const unsigned long long app = __ballot(append);
-            if (append) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(app >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(app), 0u));
-                hit_list[region_base + hit_n + rank] = make_float4(t, __int_as_float(code), __uint_as_float(j0 + lane), 0.f);
-            }
-            hit_n += static_cast<uint32_t>(__popcll(app));
-        }
+        if (RENDER)
+            append_hit(hit_list, region_base, rg.shift, append, other,
+                       make_float4(t, __int_as_float(code), __uint_as_float(j0 + lane), 0.f), hit_n0, hit_n1);
       }
-      if (RENDER && lane == 0) rg.counts_out[r] = hit_n;
+      if (RENDER && lane == 0) rg.counts_out[r] = hit_n0 | (hit_n1 << 16);
     }
 }
 
@@ -261,33 +291,33 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 // the remaining surface hits, compacted per region with ballot + prefix rank,
 // to the hit list the shade kernel consumes: (t, triangle, slot in region).
 template <int STACK, bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER>
-__global__ void __launch_bounds__(kBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
+__global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
                                                         float4 *__restrict__ hit_list, float4 *__restrict__ samples,
                                                         unsigned long long *__restrict__ nan_counter, uint32_t last_segment,
                                                         TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at)
 {
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     extern __shared__ float4 lds[];
-    int *stack = reinterpret_cast<int *>(lds);                 // STACK * kBlock entries, [entry][lane]
-    float4 *lds_nodes = lds + (STACK * kBlock) / 4;            // 4 * n_nodes lanes      (SCENE_LDS >= 1)
+    StackT *stack = reinterpret_cast<StackT *>(lds);           // STACK * kExtBlock entries, [entry][lane]
+    float4 *lds_nodes = lds + (STACK * kExtBlock * sizeof(StackT)) / 16;            // 4 * n_nodes lanes      (SCENE_LDS >= 1)
     float4 *lds_tris = lds_nodes + 4 * static_cast<size_t>(n_nodes);  // 4 * n_triangles (SCENE_LDS == 2)
     const uint32_t tid = threadIdx.x;
     if (SCENE_LDS >= 1) {
-        for (uint32_t i = tid; i < 4u * n_nodes; i += kBlock) lds_nodes[i] = sc.nodes[i];
+        for (uint32_t i = tid; i < 4u * n_nodes; i += kExtBlock) lds_nodes[i] = sc.nodes[i];
         if (SCENE_LDS >= 2)
-            for (uint32_t i = tid; i < 4u * sc.n_triangles; i += kBlock) lds_tris[i] = sc.triangles[i];
+            for (uint32_t i = tid; i < 4u * sc.n_triangles; i += kExtBlock) lds_tris[i] = sc.triangles[i];
         __syncthreads();
     }
-    const uint32_t n_waves = gridDim.x * (kBlock / 64);
+    const uint32_t n_waves = gridDim.x * (kExtBlock / 64);
     unsigned long long my_nodes = 0, my_tris = 0;
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-level diagnostics (COUNT only)
 
-    for (uint32_t k = blockIdx.x * (kBlock / 64) + (tid >> 6); k < rg.n_regions; k += n_waves) {
+    for (uint32_t k = blockIdx.x * (kExtBlock / 64) + (tid >> 6); k < rg.n_regions; k += n_waves) {
         const uint32_t r = region_of(rg, k);
         const uint32_t n = rg.counts_in[r];
         const uint32_t region_base = r << rg.shift;
         uint32_t next = 0;   // wave-uniform: rays of the region handed out so far
-        uint32_t hit_n = 0;  // wave-uniform: surface hits appended to the region's hit list
+        uint32_t hit_n0 = 0, hit_n1 = 0;  // wave-uniform: surface hits appended to the two ends of the region's hit list
 
         // per-lane ray state
         bool active = false, done = false;
@@ -316,9 +346,10 @@ __global__ void __launch_bounds__(kBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneVie
                         const float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
                         const float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
                         const float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
-                        ix = 1.0f / dx;
-                        iy = 1.0f / dy;
-                        iz = 1.0f / dz;
+                        // The hardware reciprocal (1 ulp) is enough: the slabs are padded by far more.
+                        ix = __builtin_amdgcn_rcpf(dx);
+                        iy = __builtin_amdgcn_rcpf(dy);
+                        iz = __builtin_amdgcn_rcpf(dz);
                         const float pad = 7.62939453125e-6f *
                                           fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), sc.scene_radius));
                         const float mx = pad * fabsf(ix), my_ = pad * fabsf(iy), mz = pad * fabsf(iz);
@@ -382,7 +413,7 @@ __global__ void __launch_bounds__(kBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneVie
                     const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
                     if (hit0 && hit1) {
                         const bool first0 = tn0 <= tn1;
-                        stack[sp * kBlock + tid] = first0 ? c1 : c0;
+                        stack[sp * kExtBlock + tid] = static_cast<StackT>(first0 ? c1 : c0);
                         ++sp;
                         node = first0 ? c0 : c1;
                     } else if (hit0) {
@@ -393,7 +424,7 @@ __global__ void __launch_bounds__(kBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneVie
                         done = true;
                     } else {
                         --sp;
-                        node = stack[sp * kBlock + tid];
+                        node = stack[sp * kExtBlock + tid];
                     }
                 }
             }
@@ -422,7 +453,7 @@ __global__ void __launch_bounds__(kBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneVie
                     done = true;
                 } else {
                     --sp;
-                    node = stack[sp * kBlock + tid];
+                    node = stack[sp * kExtBlock + tid];
                 }
             }
 
@@ -430,6 +461,7 @@ __global__ void __launch_bounds__(kBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneVie
             bool append = false;
             float hit_t = 0.f;
             int hit_code = -1;
+            bool other = false;
             if (active && done) {
                 if (EXACT && !(h.t < __builtin_inff())) {
                     for (uint32_t j = 0; j < sc.n_triangles; ++j) {
@@ -439,7 +471,8 @@ __global__ void __launch_bounds__(kBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneVie
                     }
                 }
                 hit_t = h.t;
-                hit_code = h.id;
+                hit_code = h.id < 0 ? h.id : (h.id & kIdMask);
+                other = h.id >= 0 && (h.id & kClassBit) != 0;
                 test_lights(sc, o, d, hit_t, hit_code);
                 if (!RENDER) {
                     results[slot] = make_float2(hit_t, __int_as_float(hit_code));
@@ -458,18 +491,11 @@ __global__ void __launch_bounds__(kBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneVie
                 }
                 active = false;
             }
-            if (RENDER) {
-                const unsigned long long app = __ballot(append);
-                if (append) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(app >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(app), 0u));
-                    hit_list[region_base + hit_n + rank] =
-                        make_float4(hit_t, __int_as_float(hit_code), __uint_as_float(slot - region_base), 0.f);
-                }
-                hit_n += static_cast<uint32_t>(__popcll(app));
-            }
+            if (RENDER)
+                append_hit(hit_list, region_base, rg.shift, append, other,
+                           make_float4(hit_t, __int_as_float(hit_code), __uint_as_float(slot - region_base), 0.f), hit_n0, hit_n1);
         }
-        if (RENDER && (tid & 63u) == 0) rg.counts_out[r] = hit_n;
+        if (RENDER && (tid & 63u) == 0) rg.counts_out[r] = hit_n0 | (hit_n1 << 16);
     }
     if (COUNT) {
         atomicAdd(tc.nodes_visited, my_nodes);
@@ -794,14 +820,42 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
     for (uint32_t k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); k < rg.n_regions; k += n_waves) {
       const uint32_t r = region_of(rg, k);
-      const uint32_t n = rg.counts_in[r];
+      // hits on purely diffuse surfaces from the region's first slot upwards (low half of the count),
+      // all others from its last slot downwards (high half).  Full batches of 64 of one kind, then of
+      // the other; what is left of both shares one batch when it fits.
+      const uint32_t packed = rg.counts_in[r];
+      const uint32_t n0 = packed & 0xFFFFu, n1 = packed >> 16;
+      const uint32_t full0 = n0 >> 6, full1 = n1 >> 6, rem0 = n0 & 63u, rem1 = n1 & 63u;
+      const bool merged = rem0 + rem1 <= 64u;
+      const uint32_t batches = full0 + full1 + (merged ? ((rem0 + rem1) != 0u ? 1u : 0u) : 2u);
       const uint32_t region_base = r << rg.shift;
+      const uint32_t last_slot = (1u << rg.shift) - 1u;
       uint32_t out_n = 0;  // wave-uniform: survivors written to this region so far
-      for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+      for (uint32_t bt = 0; bt < batches; ++bt) {
+        // which hit this lane takes: index from the front (take0) or from the back (take1) of the list
+        bool take0 = false, take1 = false;
+        uint32_t j = 0;
+        if (bt < full0) {
+            take0 = true;
+            j = (bt << 6) + lane;
+        } else if (bt < full0 + full1) {
+            take1 = true;
+            j = ((bt - full0) << 6) + lane;
+        } else if (merged) {
+            take0 = lane < rem0;
+            take1 = !take0 && lane < rem0 + rem1;
+            j = take0 ? (full0 << 6) + lane : (full1 << 6) + (lane - rem0);
+        } else if (bt == full0 + full1) {
+            take0 = lane < rem0;
+            j = (full0 << 6) + lane;
+        } else {
+            take1 = lane < rem1;
+            j = (full1 << 6) + lane;
+        }
         bool alive = false;
         float4 o0, o1, o2;
-        if (j0 + lane < n) {
-            const float4 rec = hit_list[region_base + j0 + lane];
+        if (take0 || take1) {
+            const float4 rec = hit_list[region_base + (take1 ? last_slot - j : j)];
             const uint32_t i = region_base + __float_as_uint(rec.z);
             const float4 a = in.p0[i], b = in.p1[i], c = in.p2[i];
             const int code = __float_as_int(rec.y);
@@ -874,8 +928,28 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
                                                         uint32_t n_pixels, uint32_t n_iterations,
                                                         const uint32_t *__restrict__ counts, uint32_t n_rows,
                                                         uint32_t n_regions, uint32_t pitch,
-                                                        unsigned long long *__restrict__ segments_total)
+                                                        unsigned long long *__restrict__ segments_total,
+                                                        unsigned long long *__restrict__ shade_totals)
 {
+    {
+        // surface hits shaded in this batch and the 64-lane batches the shade kernel formed of them
+        // (rows n_rows + 1 ... 2 * n_rows - 1 hold the packed hit counts of the bounces that are shaded)
+        unsigned long long hits = 0, batches = 0;
+        for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < (n_rows - 1u) * n_regions; k += gridDim.x * kBlock) {
+            const uint32_t packed = counts[(n_rows + 1u + k / n_regions) * pitch + (k % n_regions)];
+            const uint32_t n0 = packed & 0xFFFFu, n1 = packed >> 16, rem0 = n0 & 63u, rem1 = n1 & 63u;
+            hits += n0 + n1;
+            batches += (n0 >> 6) + (n1 >> 6) + (rem0 + rem1 <= 64u ? (rem0 + rem1 != 0u ? 1u : 0u) : 2u);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            hits += __shfl_down(hits, off);
+            batches += __shfl_down(batches, off);
+        }
+        if ((threadIdx.x & 63u) == 0 && hits != 0) {
+            atomicAdd(shade_totals, hits);
+            atomicAdd(shade_totals + 1, batches);
+        }
+    }
     {
         // segments of this batch = sum of all live counts of all bounces
         unsigned long long s = 0;
@@ -992,12 +1066,12 @@ namespace {
 // size), so no block waits for another to retire, and never more waves than
 // there are regions to hand out.
 template <typename K>
-uint32_t resident_grid(K kernel, size_t lds_bytes, LaunchShape g)
+uint32_t resident_grid(K kernel, size_t lds_bytes, LaunchShape g, int block = kBlock)
 {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     const uint32_t resident = g.n_cus * static_cast<uint32_t>(per_cu);
-    const uint32_t needed = (g.wave_items + (kBlock / 64) - 1) / (kBlock / 64);
+    const uint32_t needed = (g.wave_items + (block / 64) - 1) / (block / 64);
     return needed < resident ? (needed < 1 ? 1 : needed) : resident;
 }
 }  // namespace
@@ -1034,9 +1108,9 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     const bool counting = tc.nodes_visited != nullptr;
     // Dynamic LDS: the per-lane stacks, then as much of the scene as fits in the
     // 64 KiB a block may ask for without opting in to more.
-    const size_t stack_bytes = static_cast<size_t>(stack_entries <= 16 ? 16 : (stack_entries <= 32 ? 32 : 64)) * kBlock * 4;
+    const size_t stack_bytes = static_cast<size_t>(stack_entries <= 16 ? 16 : (stack_entries <= 32 ? 32 : 64)) * kExtBlock * sizeof(StackT);
     const size_t node_bytes = static_cast<size_t>(n_nodes) * 64, tri_bytes = static_cast<size_t>(scene.n_triangles) * 64;
-    const size_t budget = 64 * 1024;
+    const size_t budget = PT_LDS_BUDGET;
     int lds_mode = 0;
     if (scene_in_lds && stack_bytes + node_bytes + tri_bytes <= budget)
         lds_mode = 2;
@@ -1044,9 +1118,15 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         lds_mode = 1;
     const size_t lds_bytes = stack_bytes + (lds_mode >= 1 ? node_bytes : 0) + (lds_mode >= 2 ? tri_bytes : 0);
 #define PT_LAUNCH_EXTEND2(S, C, E, L, R)                                                                           \
-    hipLaunchKernelGGL((k_extend_bvh<S, C, E, L, R>), dim3(resident_grid(k_extend_bvh<S, C, E, L, R>, lds_bytes, g)),  \
-                       dim3(kBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples, out.nan_counter, last, \
-                       tc, n_nodes, refill_at)
+    do {                                                                                                          \
+        if (lds_bytes > 64 * 1024)                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_bvh<S, C, E, L, R>),                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));     \
+        hipLaunchKernelGGL((k_extend_bvh<S, C, E, L, R>),                                                         \
+                           dim3(resident_grid(k_extend_bvh<S, C, E, L, R>, lds_bytes, g, kExtBlock)),               \
+                           dim3(kExtBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples,            \
+                           out.nan_counter, last, tc, n_nodes, refill_at);                                        \
+    } while (0)
 #define PT_LAUNCH_EXTEND1(S, L)                                                                                    \
     do {                                                                                                          \
         if (exact_parallel)                                                                                       \
@@ -1086,10 +1166,10 @@ void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions 
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
-                       uint32_t pitch, unsigned long long *segments_total)
+                       uint32_t pitch, unsigned long long *segments_total, unsigned long long *shade_totals)
 {
     hipLaunchKernelGGL(k_accumulate, dim3(g.blocks), dim3(kBlock), 0, s, samples, sum, n_pixels, n_iterations, counts,
-                       n_rows, n_regions, pitch, segments_total);
+                       n_rows, n_regions, pitch, segments_total, shade_totals);
 }
 
 void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *hits, int32_t *ids,

@@ -119,7 +119,7 @@ struct pt_renderer {
     uint32_t region_pitch = 0;                // regions the queues hold at full capacity
     uint32_t region_shift = 10;               // log2(slots per region)
     bool scene_in_lds = true;                 // extend keeps nodes (and triangles) in LDS when they fit
-    unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics
+    unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics [12] hits shaded [13] shade batches
 
     // pt_read_hit_ids / pt_trace_rays report hits at t = +inf on exactly
     // parallel triangles like the reference does (see k_extend_bvh).
@@ -185,7 +185,8 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
     r->region_pitch = static_cast<uint32_t>((r->capacity + (size_t(1) << r->region_shift) - 1) >> r->region_shift);
     // rows 0..depth: live rays per region and bounce; rows depth+1..2*depth: surface hits per region and bounce
     PT_HIP(hipMalloc(&r->d_counts, static_cast<size_t>(2 * r->cfg.max_depth + 1) * r->region_pitch * sizeof(uint32_t)));
-    PT_HIP(hipMalloc(&r->d_hits, r->capacity * sizeof(float4)));
+    // whole regions: the hit list of a region is filled from both of its ends
+    PT_HIP(hipMalloc(&r->d_hits, (static_cast<size_t>(r->region_pitch) << r->region_shift) * sizeof(float4)));
     PT_HIP(hipMalloc(&r->d_samples, r->capacity * sizeof(float4)));
     PT_HIP(hipMalloc(&r->d_sum, n_pixels * sizeof(float4)));
     PT_HIP(hipMemsetAsync(r->d_sum, 0, n_pixels * sizeof(float4), r->stream));
@@ -237,7 +238,7 @@ pt::LaunchShape shape_for(const pt_renderer *r, size_t work_items)
 int reset_accumulation(pt_renderer *r)
 {
     PT_HIP(hipMemsetAsync(r->d_sum, 0, static_cast<size_t>(r->width) * r->height * sizeof(float4), r->stream));
-    PT_HIP(hipMemsetAsync(r->d_counters, 0, 12 * sizeof(unsigned long long), r->stream));
+    PT_HIP(hipMemsetAsync(r->d_counters, 0, 14 * sizeof(unsigned long long), r->stream));
     r->local_iterations = 0;
     r->paths = 0;
     for (int k = 0; k < 4; ++k) {
@@ -314,7 +315,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     {
         Timed t(r, 3);
         pt::launch_accumulate(r->stream, shape_for(r, n_pixels), r->d_samples, r->d_sum, static_cast<uint32_t>(n_pixels), kb,
-                              r->d_counts, depth, regions_for(r, n_paths, 0, -1).n_regions, r->region_pitch, r->d_counters);
+                              r->d_counts, depth, regions_for(r, n_paths, 0, -1).n_regions, r->region_pitch, r->d_counters, r->d_counters + 12);
     }
     PT_HIP(hipGetLastError());
     if (r->cfg.profile & 1u) {
@@ -404,6 +405,17 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
     };
     int rc;
     if ((rc = upload(&r->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(pt::BvhNode)))) return rc;
+    // Sorting hint for the shade kernel: bit 30 of a record's triangle index marks surfaces that are not
+    // purely diffuse (scene.h material model: metallic > 0 or roughness < 1 reach the microfacet lobes).
+    for (pt::BvhTriangle &tri : bvh.triangles) {
+        const uint32_t m = sc->material_map[tri.original];
+        bool diffuse = false;
+        if (m < sc->n_materials) {
+            const float *mat = sc->materials + 8 * static_cast<size_t>(m);
+            diffuse = mat[4] <= 0.f && mat[3] >= 1.f;  // metallic, roughness
+        }
+        if (!diffuse) tri.original |= pt::kHitClassBit;
+    }
     if ((rc = upload(&r->d_tris, bvh.triangles.data(), bvh.triangles.size() * sizeof(pt::BvhTriangle)))) return rc;
     if ((rc = upload(&r->d_shade, shade.data(), shade.size() * sizeof(pt::ShadeTriangle)))) return rc;
     if ((rc = upload(&r->d_materials, sc->materials, static_cast<size_t>(sc->n_materials) * 32))) return rc;
@@ -649,7 +661,7 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     r->device = device;
     if (const char *e = std::getenv("PT_REGION_SHIFT")) {  // tuning experiments only
         int v = std::atoi(e);
-        if (v >= 6 && v <= 16) r->region_shift = static_cast<uint32_t>(v);
+        if (v >= 6 && v <= 15) r->region_shift = static_cast<uint32_t>(v);
     }
     if (const char *e = std::getenv("PT_SCENE_LDS")) r->scene_in_lds = std::atoi(e) != 0;  // tuning experiments only
     hipDeviceProp_t prop;
@@ -665,7 +677,7 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipStreamCreate failed"));
     if ((rc = upload_scene(r, scene)) != PT_OK) return bail(rc);
-    if (hipMalloc(&r->d_counters, 12 * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMalloc(&r->d_counters, 14 * sizeof(unsigned long long)) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipMalloc failed"));
     if ((rc = alloc_paths(r, cfg.width, cfg.height)) != PT_OK) return bail(rc);
     r->cam.tan_half_fov = tan_half_fov(cfg.fov_y_degrees);
@@ -1030,7 +1042,7 @@ int pt_get_stats(pt_renderer *r, pt_stats *s)
     PT_HIP(hipSetDevice(r->device));
     PT_HIP(hipStreamSynchronize(r->stream));
     drain_events(r);
-    unsigned long long c[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long c[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     PT_HIP(hipMemcpy(c, r->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     std::memset(s, 0, sizeof(*s));
     s->iterations = r->local_iterations;
@@ -1055,6 +1067,8 @@ int pt_get_stats(pt_renderer *r, pt_stats *s)
     s->launches_accumulate = r->launches[3];
     s->sah_cost = r->sah_cost;
     for (int k = 0; k < 8; ++k) s->extend_diag[k] = c[4 + k];
+    s->hits_shaded = c[12];
+    s->shade_batches = c[13];
     return PT_OK;
 }
 

@@ -1,9 +1,9 @@
-import sys, os, glob
+"""Runs bench.py under several environment settings (tuning experiments)."""
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench_quick import run
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-libs = [None] + sorted(glob.glob(os.path.join(ROOT, "pathtracer_amd/variants/*.so")))
-for lib in libs:
-    env = {"PT_AMD_LIB": lib} if lib else {}
+# usage: bench_env.py "A=1 B=2" "A=3" ...   ("-" = defaults)
+for spec in sys.argv[1:] or ["-"]:
+    env = {} if spec == "-" else dict(kv.split("=", 1) for kv in spec.split())
     for scene in ("Box", "Veggie"):
-        run(env, ["--scene", scene, "--spp-per-step", "16", "--steps", "8", "--warmup", "2"], f"{os.path.basename(lib) if lib else 'default'} {scene}")
+        run(env, ["--scene", scene, "--steps", "8", "--warmup", "2"], f"[{spec}] {scene}")

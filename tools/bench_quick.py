@@ -7,8 +7,10 @@ def run(env_extra, args, label):
         d = json.loads(out.stdout.strip().splitlines()[-1])
         k = d["roofline"]["kernels"]
         print(f"{label}: {d['value']:.0f} Mpaths/s  extend {k['extend']['ms_total']/k['extend']['launches']*1e3:.0f} us  shade {k['shade']['ms_total']/k['shade']['launches']*1e3:.0f} us /launch; gates {d['gates']['primary_hit_ids_bit_exact_vs_reference']}", flush=True)
-    except Exception as e:
-        print("failed", label, out.stderr[-800:])
+    except Exception:
+        # A failed GPU run ends the whole sweep: nothing more is started on the card.
+        print("failed", label, out.stderr[-800:], flush=True)
+        sys.exit(1)
 if __name__ == "__main__":
     for scene in ("Box", "Veggie"):
         for lds in ("0", "1"):
