@@ -312,15 +312,19 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
     unsigned long long my_nodes = 0, my_tris = 0;
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-level diagnostics (COUNT only)
 
-    for (uint32_t k = blockIdx.x * (kExtBlock / 64) + (tid >> 6); k < rg.n_regions; k += n_waves) {
-        const uint32_t r = region_of(rg, k);
-        const uint32_t n = rg.counts_in[r];
-        const uint32_t region_base = r << rg.shift;
-        uint32_t next = 0;   // wave-uniform: rays of the region handed out so far
-        uint32_t hit_n0 = 0, hit_n1 = 0;  // wave-uniform: surface hits appended to the two ends of the region's hit list
-
+    // The wave streams through its regions: when the current one has handed out
+    // all its rays, idle lanes start on the next one while the last rays of the
+    // previous region are still in flight (at most two regions at a time, told
+    // apart by one parity bit per lane), so only the very end of the kernel
+    // runs with thinning lanes.
+    uint32_t k = blockIdx.x * (kExtBlock / 64) + (tid >> 6);  // next turn of this wave
+    uint32_t cur_r = 0, cur_n = 0, cur_base = 0, cur_next = 0, cur_h0 = 0, cur_h1 = 0;  // region being handed out
+    uint32_t prv_r = 0, prv_base = 0, prv_h0 = 0, prv_h1 = 0;                           // region before it
+    bool cur_valid = false, prv_valid = false;
+    bool cur_gen = false;  // parity of the current region; a lane whose gen differs works for the previous one
+    {
         // per-lane ray state
-        bool active = false, done = false;
+        bool active = false, done = false, gen = false;
         uint32_t slot = 0;
         f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
         float ix = 0.f, iy = 0.f, iz = 0.f, cnx = 0.f, cny = 0.f, cnz = 0.f, cfx = 0.f, cfy = 0.f, cfz = 0.f;
@@ -332,12 +336,28 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
             // ---- hand fresh rays to idle lanes
             const unsigned long long idle = __ballot(!active);
             const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
-            if (next < n && (n_idle >= refill_at || n_idle == 64u)) {
+            if (n_idle >= refill_at || n_idle == 64u) {
+                // Current region dry: once the previous one has no ray in flight, publish it and open the next.
+                while (cur_next >= cur_n && k < rg.n_regions && __ballot(active && gen != cur_gen) == 0ull) {
+                    if (RENDER && prv_valid && (tid & 63u) == 0) rg.counts_out[prv_r] = prv_h0 | (prv_h1 << 16);
+                    prv_r = cur_r, prv_base = cur_base, prv_h0 = cur_h0, prv_h1 = cur_h1, prv_valid = cur_valid;
+                    cur_r = region_of(rg, k);
+                    cur_n = rg.counts_in[cur_r];
+                    cur_base = cur_r << rg.shift;
+                    cur_next = 0;
+                    cur_h0 = cur_h1 = 0;
+                    cur_valid = true;
+                    cur_gen = !cur_gen;
+                    k += n_waves;
+                }
+            }
+            if (cur_next < cur_n && (n_idle >= refill_at || n_idle == 64u)) {
                 if (!active) {
-                    const uint32_t my = next + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32),
-                                                                       __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
-                    if (my < n) {
-                        slot = region_base + my;
+                    const uint32_t my = cur_next + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32),
+                                                                           __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
+                    if (my < cur_n) {
+                        gen = cur_gen;
+                        slot = cur_base + my;
                         const float4 a = q.p0[slot], b = q.p1[slot];
                         o = mk(a.x, a.y, a.z);
                         d = mk(a.w, b.x, b.y);
@@ -372,11 +392,14 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 }
                 if (COUNT) {
                     dg[6] += 1;
-                    dg[7] += min(n_idle, n - next);
+                    dg[7] += min(n_idle, cur_n - cur_next);
                 }
-                next += n_idle;
+                cur_next += n_idle;
             }
-            if (__ballot(active) == 0ull) break;
+            if (__ballot(active) == 0ull) {
+                if (cur_next >= cur_n && k >= rg.n_regions) break;  // nothing in flight and nothing left to hand out
+                continue;
+            }
             if (COUNT) {
                 dg[4] += 1;
                 dg[5] += __popcll(__ballot(active));
@@ -491,11 +514,19 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 }
                 active = false;
             }
-            if (RENDER)
-                append_hit(hit_list, region_base, rg.shift, append, other,
-                           make_float4(hit_t, __int_as_float(hit_code), __uint_as_float(slot - region_base), 0.f), hit_n0, hit_n1);
+            if (RENDER) {
+                const bool for_prev = gen != cur_gen;
+                append_hit(hit_list, cur_base, rg.shift, append && !for_prev, other,
+                           make_float4(hit_t, __int_as_float(hit_code), __uint_as_float(slot - cur_base), 0.f), cur_h0, cur_h1);
+                if (__ballot(append && for_prev) != 0ull)
+                    append_hit(hit_list, prv_base, rg.shift, append && for_prev, other,
+                               make_float4(hit_t, __int_as_float(hit_code), __uint_as_float(slot - prv_base), 0.f), prv_h0, prv_h1);
+            }
         }
-        if (RENDER && (tid & 63u) == 0) rg.counts_out[r] = hit_n0 | (hit_n1 << 16);
+        if (RENDER && (tid & 63u) == 0) {
+            if (prv_valid) rg.counts_out[prv_r] = prv_h0 | (prv_h1 << 16);
+            if (cur_valid) rg.counts_out[cur_r] = cur_h0 | (cur_h1 << 16);
+        }
     }
     if (COUNT) {
         atomicAdd(tc.nodes_visited, my_nodes);
