@@ -30,6 +30,11 @@ constexpr int kBlock = 256;
 #ifndef PT_STACK_T
 #define PT_STACK_T int
 #endif
+// 16-byte lanes between consecutive records of the LDS copy of the scene (4 = packed; 5 spreads
+// consecutive records over all banks).
+#ifndef PT_LDS_STRIDE
+#define PT_LDS_STRIDE 4
+#endif
 #ifndef PT_LDS_BUDGET
 #define PT_LDS_BUDGET (64 * 1024)
 #endif
@@ -300,12 +305,13 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
     extern __shared__ float4 lds[];
     StackT *stack = reinterpret_cast<StackT *>(lds);           // STACK * kExtBlock entries, [entry][lane]
     float4 *lds_nodes = lds + (STACK * kExtBlock * sizeof(StackT)) / 16;            // 4 * n_nodes lanes      (SCENE_LDS >= 1)
-    float4 *lds_tris = lds_nodes + 4 * static_cast<size_t>(n_nodes);  // 4 * n_triangles (SCENE_LDS == 2)
+    float4 *lds_tris = lds_nodes + PT_LDS_STRIDE * static_cast<size_t>(n_nodes);  // n_triangles records (SCENE_LDS == 2)
     const uint32_t tid = threadIdx.x;
     if (SCENE_LDS >= 1) {
-        for (uint32_t i = tid; i < 4u * n_nodes; i += kExtBlock) lds_nodes[i] = sc.nodes[i];
+        for (uint32_t i = tid; i < 4u * n_nodes; i += kExtBlock) lds_nodes[(i >> 2) * PT_LDS_STRIDE + (i & 3u)] = sc.nodes[i];
         if (SCENE_LDS >= 2)
-            for (uint32_t i = tid; i < 4u * sc.n_triangles; i += kExtBlock) lds_tris[i] = sc.triangles[i];
+            for (uint32_t i = tid; i < 4u * sc.n_triangles; i += kExtBlock)
+                lds_tris[(i >> 2) * PT_LDS_STRIDE + (i & 3u)] = sc.triangles[i];
         __syncthreads();
     }
     const uint32_t n_waves = gridDim.x * (kExtBlock / 64);
@@ -322,6 +328,8 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
     uint32_t prv_r = 0, prv_base = 0, prv_h0 = 0, prv_h1 = 0;                           // region before it
     bool cur_valid = false, prv_valid = false;
     bool cur_gen = false;  // parity of the current region; a lane whose gen differs works for the previous one
+    uint32_t nxt_r = k < rg.n_regions ? region_of(rg, k) : 0u;         // region of turn k and its ray count
+    uint32_t nxt_n = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
     {
         // per-lane ray state
         bool active = false, done = false, gen = false;
@@ -341,14 +349,17 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 while (cur_next >= cur_n && k < rg.n_regions && __ballot(active && gen != cur_gen) == 0ull) {
                     if (RENDER && prv_valid && (tid & 63u) == 0) rg.counts_out[prv_r] = prv_h0 | (prv_h1 << 16);
                     prv_r = cur_r, prv_base = cur_base, prv_h0 = cur_h0, prv_h1 = cur_h1, prv_valid = cur_valid;
-                    cur_r = region_of(rg, k);
-                    cur_n = rg.counts_in[cur_r];
+                    cur_r = nxt_r;
+                    cur_n = nxt_n;
                     cur_base = cur_r << rg.shift;
                     cur_next = 0;
                     cur_h0 = cur_h1 = 0;
                     cur_valid = true;
                     cur_gen = !cur_gen;
                     k += n_waves;
+                    // the count of the region after this one is fetched now, long before it is needed
+                    nxt_r = k < rg.n_regions ? region_of(rg, k) : 0u;
+                    nxt_n = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
                 }
             }
             if (cur_next < cur_n && (n_idle >= refill_at || n_idle == 64u)) {
@@ -414,7 +425,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 if (active && !done && node >= 0) {
                     float4 n0, n1, n2, n3;
                     if (SCENE_LDS >= 1) {
-                        const float4 *np = lds_nodes + 4 * static_cast<size_t>(node);
+                        const float4 *np = lds_nodes + PT_LDS_STRIDE * static_cast<size_t>(node);
                         n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                     } else {
                         const float4 *np = sc.nodes + 4 * static_cast<size_t>(node);
@@ -467,7 +478,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 const uint32_t first = code >> 3, cnt = code & 7u;
                 for (uint32_t j = 0; j < cnt; ++j) {
                     if (SCENE_LDS >= 2)
-                        test_triangle(lds_tris + 4 * static_cast<size_t>(first + j), o, d, h);
+                        test_triangle(lds_tris + PT_LDS_STRIDE * static_cast<size_t>(first + j), o, d, h);
                     else
                         test_triangle(sc.triangles + 4 * static_cast<size_t>(first + j), o, d, h);
                 }
@@ -849,12 +860,19 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    for (uint32_t k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); k < rg.n_regions; k += n_waves) {
-      const uint32_t r = region_of(rg, k);
+    uint32_t k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    uint32_t nxt_r = k < rg.n_regions ? region_of(rg, k) : 0u;
+    uint32_t nxt_packed = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
+    for (; k < rg.n_regions; k += n_waves) {
+      const uint32_t r = nxt_r;
       // hits on purely diffuse surfaces from the region's first slot upwards (low half of the count),
       // all others from its last slot downwards (high half).  Full batches of 64 of one kind, then of
       // the other; what is left of both shares one batch when it fits.
-      const uint32_t packed = rg.counts_in[r];
+      const uint32_t packed = nxt_packed;
+      if (k + n_waves < rg.n_regions) {  // the next region's count is fetched while this one is shaded
+          nxt_r = region_of(rg, k + n_waves);
+          nxt_packed = rg.counts_in[nxt_r];
+      }
       const uint32_t n0 = packed & 0xFFFFu, n1 = packed >> 16;
       const uint32_t full0 = n0 >> 6, full1 = n1 >> 6, rem0 = n0 & 63u, rem1 = n1 & 63u;
       const bool merged = rem0 + rem1 <= 64u;
@@ -1140,7 +1158,8 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     // Dynamic LDS: the per-lane stacks, then as much of the scene as fits in the
     // 64 KiB a block may ask for without opting in to more.
     const size_t stack_bytes = static_cast<size_t>(stack_entries <= 16 ? 16 : (stack_entries <= 32 ? 32 : 64)) * kExtBlock * sizeof(StackT);
-    const size_t node_bytes = static_cast<size_t>(n_nodes) * 64, tri_bytes = static_cast<size_t>(scene.n_triangles) * 64;
+    const size_t node_bytes = static_cast<size_t>(n_nodes) * 16 * PT_LDS_STRIDE,
+                 tri_bytes = static_cast<size_t>(scene.n_triangles) * 16 * PT_LDS_STRIDE;
     const size_t budget = PT_LDS_BUDGET;
     int lds_mode = 0;
     if (scene_in_lds && stack_bytes + node_bytes + tri_bytes <= budget)

@@ -117,7 +117,8 @@ struct pt_renderer {
     float4 *d_sum = nullptr;
     uint32_t *d_counts = nullptr;             // (max_depth + 1) rows of region_pitch live counts, one row per bounce
     uint32_t region_pitch = 0;                // regions the queues hold at full capacity
-    uint32_t region_shift = 10;               // log2(slots per region)
+    uint32_t region_shift = 10;               // log2(slots per region), chosen from the batch size
+    bool region_shift_fixed = false;          // set through the environment (experiments)
     bool scene_in_lds = true;                 // extend keeps nodes (and triangles) in LDS when they fit
     unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics [12] hits shaded [13] shade batches
 
@@ -169,8 +170,8 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
     uint32_t k = r->cfg.iterations_per_batch;
     if (k == 0) {
         // Enough paths in flight to keep 256 CUs busy after compaction has
-        // thinned the queue: about 8M slots, at most 16 samples per pixel.
-        k = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(16, (size_t(8) << 20) / std::max<size_t>(1, n_pixels))));
+        // thinned the queue: about 32M slots (4.3 GB of queues), at most 16 samples per pixel.
+        k = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(16, (size_t(32) << 20) / std::max<size_t>(1, n_pixels))));
     }
     // Path slots are 32-bit.
     while (k > 1 && n_pixels * k >= (size_t(1) << 31)) --k;
@@ -181,6 +182,14 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         PT_HIP(hipMalloc(&r->q[b].p0, r->capacity * sizeof(float4)));
         PT_HIP(hipMalloc(&r->q[b].p1, r->capacity * sizeof(float4)));
         PT_HIP(hipMalloc(&r->q[b].p2, r->capacity * sizeof(float4)));
+    }
+    if (!r->region_shift_fixed) {
+        // Region size: large regions amortise the per-region work, small ones balance the persistent waves
+        // (16 per CU).  Measured best at about three regions per wave; 256 ... 2048 slots.
+        const size_t per_wave = r->capacity / (size_t(3) * 16 * std::max<uint32_t>(1, r->n_cus));
+        uint32_t shift = 8;
+        while (shift < 11 && (size_t(2) << shift) <= per_wave) ++shift;
+        r->region_shift = shift;
     }
     r->region_pitch = static_cast<uint32_t>((r->capacity + (size_t(1) << r->region_shift) - 1) >> r->region_shift);
     // rows 0..depth: live rays per region and bounce; rows depth+1..2*depth: surface hits per region and bounce
@@ -661,7 +670,10 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     r->device = device;
     if (const char *e = std::getenv("PT_REGION_SHIFT")) {  // tuning experiments only
         int v = std::atoi(e);
-        if (v >= 6 && v <= 15) r->region_shift = static_cast<uint32_t>(v);
+        if (v >= 6 && v <= 15) {
+            r->region_shift = static_cast<uint32_t>(v);
+            r->region_shift_fixed = true;
+        }
     }
     if (const char *e = std::getenv("PT_SCENE_LDS")) r->scene_in_lds = std::atoi(e) != 0;  // tuning experiments only
     hipDeviceProp_t prop;
