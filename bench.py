@@ -18,6 +18,7 @@ Outside the timed region the same command also
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -121,6 +122,8 @@ def kernel_profile(pt, args, scene_name, device, rank, world):
     scale = st["segments"] / max(1, c["segments"])
     st["nodes_visited"] = int(c["nodes_visited"] * scale)
     st["tris_tested"] = int(c["tris_tested"] * scale)
+    d = c["extend_diag"]  # [4] rounds of the traversal loop, [5] lanes holding a ray summed over them
+    st["diag_lanes"] = d[5] / max(1, d[4])
     return st
 
 
@@ -196,9 +199,7 @@ def main():
     out = None
     if rank == 0:
         seg, paths = prof["segments"], prof["paths"]
-        # Every segment beyond a path's first follows a shaded surface hit that survived; a few more hits
-        # are shaded and die (pdf <= 0, zero throughput), so (seg - paths) is a lower bound on shaded hits.
-        shaded = seg - paths
+        shaded = prof["hits_shaded"]  # surface hits handed to the shade kernel
         extend_bytes = EXTEND_READ_PER_RAY * seg + EXTEND_WRITE_PER_HIT * shaded
         shade_bytes = SHADE_READ_PER_HIT * shaded + SHADE_WRITE_PER_SURVIVOR * shaded
         kernels = {
@@ -216,8 +217,26 @@ def main():
         achieved = kernels[dom]["achieved_GBs"]
         # counted work for the VALU view: box tests ~ 2 x 17 flops per node, triangle test ~ 85 flops
         flops = prof["nodes_visited"] * 44.0 + prof["tris_tested"] * 85.0 + seg * 60.0
+        # HBM bytes per launch and VALU figures of the same command under rocprofv3 --pmc (separate passes,
+        # FETCH_SIZE doubled for gfx950), kept with the profile summaries.
+        pmc, traffic = {}, None
+        pmc_file = os.path.join(ROOT, "profiles", f"pmc_{args.scene}_{args.width}x{args.height}.json")
+        if os.path.exists(pmc_file):
+            allk = json.load(open(pmc_file))
+            for name, m in allk.items():
+                # the render-loop instantiation: no counters, no exact-parallel pass, render mode
+                short = "extend" if re.fullmatch(r"k_extend_bvh<\d+, false, false, \d, true>", name) else \
+                    ("shade" if name == "k_shade" else None)
+                if short:
+                    pmc[short] = m
+            if dom in pmc and "hbm_read_bytes_per_launch" in pmc[dom]:
+                traffic = pmc[dom]["hbm_read_bytes_per_launch"] + pmc[dom].get("hbm_write_bytes_per_launch", 0.0)
+        occupancy = {"shade_lane_fill": prof["hits_shaded"] / max(1, 64 * prof["shade_batches"]),
+                     "extend_lanes_holding_a_ray": prof["diag_lanes"]}
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "pmc": {"source": os.path.relpath(pmc_file, ROOT) if pmc else None, **pmc},
+                    "lane_occupancy": occupancy,
                     "avg_launch_ms": kernels[dom]["avg_launch_ms"],
                     "bytes_per_launch": kernels[dom]["algorithmic_bytes"] / max(1, kernels[dom]["launches"]),
                     "valu_view": {"extend_counted_gflop": flops / 1e9,

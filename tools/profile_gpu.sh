@@ -7,10 +7,11 @@ TAG=${1:-r01}; shift || true
 export TMPDIR=/tmp
 OUT=gpurun_out/prof/$TAG
 mkdir -p "$OUT"
-BENCH="python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extra $*"
+# PROG overrides the profiled command (default: a short bench.py run with the given arguments)
+BENCH=${PROG:-"python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extra $*"}
 run() { # name, rocprof args...
   local name=$1; shift
-  timeout -s KILL 150 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.json" 2> "$OUT/$name.err"
+  timeout -s KILL ${PASS_LIMIT:-150} rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.json" 2> "$OUT/$name.err"
   local rc=$?
   echo "$name rc=$rc"
   return $rc
