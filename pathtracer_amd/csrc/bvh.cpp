@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -9,8 +10,18 @@ namespace pt {
 
 namespace {
 
-constexpr uint32_t kLeafMax = 4;
+// Largest leaf.  (PT_BVH_LEAF: tuning experiments only, 1..7.)
+const uint32_t kLeafMax = [] {
+    const char *e = std::getenv("PT_BVH_LEAF");
+    const int v = e ? std::atoi(e) : 4;
+    return static_cast<uint32_t>(v < 1 ? 1 : (v > 7 ? 7 : v));
+}();
 constexpr int kBins = 16;
+// Cost of one inner-node step in units of one triangle test.  (PT_BVH_CT: tuning experiments only.)
+const double kTraversalCost = [] {
+    const char *e = std::getenv("PT_BVH_CT");
+    return e ? std::atof(e) : 1.0;
+}();
 
 struct Box {
     float lo[3], hi[3];
@@ -73,7 +84,7 @@ struct Builder {
         const uint32_t n = end - begin;
         int32_t self = static_cast<int32_t>(tmp.size());
         tmp.push_back(node);
-        if (n <= kLeafMax) {
+        if (n <= 1u || (n <= kLeafMax && (median_only || level >= 48))) {
             tmp[self].first = begin;
             tmp[self].count = n;
             return self;
@@ -126,6 +137,14 @@ struct Builder {
                         best_bin = b;
                     }
                 }
+            }
+            // A small group stays a leaf unless splitting it pays for the extra box test
+            // (surface-area heuristic: kTraversalCost box tests against saved triangle tests).
+            if (n <= kLeafMax && (best_axis < 0 || double(n) * node.box.half_area() <=
+                                                       kTraversalCost * node.box.half_area() + best)) {
+                tmp[self].first = begin;
+                tmp[self].count = n;
+                return self;
             }
             if (best_axis >= 0) {
                 const float lo = cbox.lo[best_axis];
@@ -198,6 +217,46 @@ uint32_t flatten(const std::vector<TmpNode> &tmp, int32_t t, std::vector<BvhNode
     return 1 + std::max(d0, d1);
 }
 
+// Renumbers the inner nodes: the top of the tree breadth-first (so that every
+// prefix of the node array is closed under "parent of", which lets the
+// traversal kernel keep a prefix in LDS), the subtrees below it in pre-order
+// (a subtree's nodes stay together in memory).
+void renumber_top_breadth_first(std::vector<BvhNode> *nodes, size_t top)
+{
+    const size_t n = nodes->size();
+    if (n <= 2) return;
+    std::vector<int32_t> order;  // new index -> old index
+    order.reserve(n);
+    std::vector<int32_t> queue{0};
+    size_t head = 0;
+    while (head < queue.size() && order.size() < top) {
+        const int32_t old = queue[head++];
+        order.push_back(old);
+        for (int c = 0; c < 2; ++c)
+            if ((*nodes)[old].child[c] >= 0) queue.push_back((*nodes)[old].child[c]);
+    }
+    std::vector<int32_t> todo;
+    for (; head < queue.size(); ++head) {
+        todo.push_back(queue[head]);
+        while (!todo.empty()) {
+            const int32_t old = todo.back();
+            todo.pop_back();
+            order.push_back(old);
+            for (int c = 1; c >= 0; --c)
+                if ((*nodes)[old].child[c] >= 0) todo.push_back((*nodes)[old].child[c]);
+        }
+    }
+    std::vector<int32_t> new_of_old(n);
+    for (size_t i = 0; i < n; ++i) new_of_old[order[i]] = static_cast<int32_t>(i);
+    std::vector<BvhNode> out(n);
+    for (size_t i = 0; i < n; ++i) {
+        out[i] = (*nodes)[order[i]];
+        for (int c = 0; c < 2; ++c)
+            if (out[i].child[c] >= 0) out[i].child[c] = new_of_old[out[i].child[c]];
+    }
+    nodes->swap(out);
+}
+
 }  // namespace
 
 void build_bvh(const float *vertices, const uint32_t *ids, uint32_t n_triangles, uint32_t max_depth, Bvh *out)
@@ -240,6 +299,7 @@ void build_bvh(const float *vertices, const uint32_t *ids, uint32_t n_triangles,
         }
         if (out->depth <= max_depth) break;
     }
+    renumber_top_breadth_first(&out->nodes, 4096);
 
     double root_area = scene.half_area();
     double cost = 0.0;

@@ -85,7 +85,7 @@ struct ExtendOutput {
     bool exact_parallel;
 };
 
-// stack_entries selects the traversal-stack instantiation (16, 32 or 64).
+// stack_entries: entries of the per-lane traversal stack in LDS (>= BVH depth).
 void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
                    Regions regions, PathQueue q, const ExtendOutput &out, TraversalCounters tc, uint32_t n_nodes,
                    bool scene_in_lds);

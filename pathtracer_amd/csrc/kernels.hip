@@ -35,9 +35,6 @@ constexpr int kBlock = 256;
 #ifndef PT_LDS_STRIDE
 #define PT_LDS_STRIDE 4
 #endif
-#ifndef PT_LDS_BUDGET
-#define PT_LDS_BUDGET (64 * 1024)
-#endif
 constexpr int kExtBlock = PT_EXT_BLOCK;
 using StackT = PT_STACK_T;
 // Minimum waves per SIMD the register allocator must leave room for (second
@@ -260,7 +257,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 // BVH traversal.  Each lane keeps its stack of deferred children in LDS,
 // laid out [entry][lane] so that a push/pop of all lanes touches consecutive
 // banks.  The stack can never hold more than one entry per inner level of the
-// tree, and the host instantiates STACK >= tree depth.
+// tree; the host passes stack_entries >= tree depth.
 //
 // Box test: the reference accepts hit points that lie a few ulp outside the
 // exact triangle, so a box may only be culled when the ray misses it by a
@@ -286,8 +283,11 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 // test its triangles.
 //
 // SCENE_LDS: 0 = nodes and triangles are read from global memory (L1/L2);
-// 1 = the block keeps a copy of the node array in LDS; 2 = nodes and
-// triangles.  The host picks the largest variant that fits beside the stacks.
+// 1 = the block keeps a copy of the first n_lds_nodes nodes in LDS (the host
+// numbers the top of the tree breadth-first, so any prefix is the part every
+// ray walks through) and reads deeper nodes from global memory; 3 = the whole
+// node array; 2 = all nodes and all triangles.  The host picks the variant by
+// the LDS a block may use without costing occupancy.
 //
 // RENDER = false (readbacks): every ray's (t, hit code) goes to results[slot].
 // RENDER = true (the render loop): the kernel also ends the paths that end
@@ -295,21 +295,23 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 // that escapes or sits on the last allowed segment adds nothing -- and appends
 // the remaining surface hits, compacted per region with ballot + prefix rank,
 // to the hit list the shade kernel consumes: (t, triangle, slot in region).
-template <int STACK, bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER>
+template <bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER>
 __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
                                                         float4 *__restrict__ hit_list, float4 *__restrict__ samples,
                                                         unsigned long long *__restrict__ nan_counter, uint32_t last_segment,
-                                                        TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at)
+                                                        TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
+                                                        uint32_t stack_entries, uint32_t n_lds_nodes)
 {
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     extern __shared__ float4 lds[];
-    StackT *stack = reinterpret_cast<StackT *>(lds);           // STACK * kExtBlock entries, [entry][lane]
-    float4 *lds_nodes = lds + (STACK * kExtBlock * sizeof(StackT)) / 16;            // 4 * n_nodes lanes      (SCENE_LDS >= 1)
-    float4 *lds_tris = lds_nodes + PT_LDS_STRIDE * static_cast<size_t>(n_nodes);  // n_triangles records (SCENE_LDS == 2)
+    StackT *stack = reinterpret_cast<StackT *>(lds);           // stack_entries * kExtBlock entries, [entry][lane]
+    float4 *lds_nodes = lds + (stack_entries * kExtBlock * sizeof(StackT)) / 16;  // the first n_lds_nodes nodes
+    float4 *lds_tris = lds_nodes + PT_LDS_STRIDE * static_cast<size_t>(n_lds_nodes);  // all triangles (SCENE_LDS == 2)
     const uint32_t tid = threadIdx.x;
     if (SCENE_LDS >= 1) {
-        for (uint32_t i = tid; i < 4u * n_nodes; i += kExtBlock) lds_nodes[(i >> 2) * PT_LDS_STRIDE + (i & 3u)] = sc.nodes[i];
-        if (SCENE_LDS >= 2)
+        for (uint32_t i = tid; i < 4u * n_lds_nodes; i += kExtBlock)
+            lds_nodes[(i >> 2) * PT_LDS_STRIDE + (i & 3u)] = sc.nodes[i];
+        if (SCENE_LDS == 2)
             for (uint32_t i = tid; i < 4u * sc.n_triangles; i += kExtBlock)
                 lds_tris[(i >> 2) * PT_LDS_STRIDE + (i & 3u)] = sc.triangles[i];
         __syncthreads();
@@ -424,7 +426,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 }
                 if (active && !done && node >= 0) {
                     float4 n0, n1, n2, n3;
-                    if (SCENE_LDS >= 1) {
+                    if (SCENE_LDS >= 2 || (SCENE_LDS == 1 && static_cast<uint32_t>(node) < n_lds_nodes)) {
                         const float4 *np = lds_nodes + PT_LDS_STRIDE * static_cast<size_t>(node);
                         n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                     } else {
@@ -477,7 +479,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 const uint32_t code = ~static_cast<uint32_t>(node);
                 const uint32_t first = code >> 3, cnt = code & 7u;
                 for (uint32_t j = 0; j < cnt; ++j) {
-                    if (SCENE_LDS >= 2)
+                    if (SCENE_LDS == 2)
                         test_triangle(lds_tris + PT_LDS_STRIDE * static_cast<size_t>(first + j), o, d, h);
                     else
                         test_triangle(sc.triangles + 4 * static_cast<size_t>(first + j), o, d, h);
@@ -1155,57 +1157,59 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         return;
     }
     const bool counting = tc.nodes_visited != nullptr;
-    // Dynamic LDS: the per-lane stacks, then as much of the scene as fits in the
-    // 64 KiB a block may ask for without opting in to more.
-    const size_t stack_bytes = static_cast<size_t>(stack_entries <= 16 ? 16 : (stack_entries <= 32 ? 32 : 64)) * kExtBlock * sizeof(StackT);
-    const size_t node_bytes = static_cast<size_t>(n_nodes) * 16 * PT_LDS_STRIDE,
-                 tri_bytes = static_cast<size_t>(scene.n_triangles) * 16 * PT_LDS_STRIDE;
-    const size_t budget = PT_LDS_BUDGET;
+    // Dynamic LDS: the per-lane stacks, then as much of the scene as a block may hold while four blocks
+    // (16 waves) still fit on a CU: all nodes and triangles, else all nodes, else the top of the tree.
+    static const size_t budget = [] {
+        const char *e = std::getenv("PT_LDS_BUDGET_KB");  // tuning experiments only
+        return static_cast<size_t>(e ? std::atoi(e) : 40) * 1024;
+    }();
+    const size_t stack_bytes = static_cast<size_t>(stack_entries) * kExtBlock * sizeof(StackT);
+    const size_t record = 16 * PT_LDS_STRIDE;
+    const size_t node_bytes = static_cast<size_t>(n_nodes) * record, tri_bytes = static_cast<size_t>(scene.n_triangles) * record;
     int lds_mode = 0;
-    if (scene_in_lds && stack_bytes + node_bytes + tri_bytes <= budget)
+    uint32_t n_lds_nodes = 0;
+    if (scene_in_lds && stack_bytes + node_bytes + tri_bytes <= budget) {
         lds_mode = 2;
-    else if (scene_in_lds && stack_bytes + node_bytes <= budget)
+        n_lds_nodes = n_nodes;
+    } else if (scene_in_lds && stack_bytes + node_bytes <= budget) {
+        lds_mode = 3;
+        n_lds_nodes = n_nodes;
+    } else if (scene_in_lds && stack_bytes + 64 * record <= budget) {
         lds_mode = 1;
-    const size_t lds_bytes = stack_bytes + (lds_mode >= 1 ? node_bytes : 0) + (lds_mode >= 2 ? tri_bytes : 0);
-#define PT_LAUNCH_EXTEND2(S, C, E, L, R)                                                                           \
+        n_lds_nodes = static_cast<uint32_t>((budget - stack_bytes) / record);
+    }
+    const size_t lds_bytes = stack_bytes + n_lds_nodes * record + (lds_mode == 2 ? tri_bytes : 0);
+#define PT_LAUNCH_EXTEND2(C, E, L, R)                                                                              \
     do {                                                                                                          \
         if (lds_bytes > 64 * 1024)                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_bvh<S, C, E, L, R>),                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_bvh<C, E, L, R>),                     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));     \
-        hipLaunchKernelGGL((k_extend_bvh<S, C, E, L, R>),                                                         \
-                           dim3(resident_grid(k_extend_bvh<S, C, E, L, R>, lds_bytes, g, kExtBlock)),               \
-                           dim3(kExtBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples,            \
-                           out.nan_counter, last, tc, n_nodes, refill_at);                                        \
+        hipLaunchKernelGGL((k_extend_bvh<C, E, L, R>),                                                            \
+                           dim3(resident_grid(k_extend_bvh<C, E, L, R>, lds_bytes, g, kExtBlock)), dim3(kExtBlock), \
+                           lds_bytes, s, scene, regions, q, out.hit_list, out.samples, out.nan_counter, last, tc,  \
+                           n_nodes, refill_at, stack_entries, n_lds_nodes);                                       \
     } while (0)
-#define PT_LAUNCH_EXTEND1(S, L)                                                                                    \
+#define PT_LAUNCH_EXTEND1(L)                                                                                       \
     do {                                                                                                          \
         if (exact_parallel)                                                                                       \
-            PT_LAUNCH_EXTEND2(S, false, true, L, false);                                                          \
+            PT_LAUNCH_EXTEND2(false, true, L, false);                                                             \
         else if (!render)                                                                                         \
-            PT_LAUNCH_EXTEND2(S, false, false, L, false);                                                         \
+            PT_LAUNCH_EXTEND2(false, false, L, false);                                                            \
         else if (counting)                                                                                        \
-            PT_LAUNCH_EXTEND2(S, true, false, L, true);                                                           \
+            PT_LAUNCH_EXTEND2(true, false, L, true);                                                              \
         else                                                                                                      \
-            PT_LAUNCH_EXTEND2(S, false, false, L, true);                                                          \
+            PT_LAUNCH_EXTEND2(false, false, L, true);                                                             \
     } while (0)
-#define PT_LAUNCH_EXTEND(S)                                                                                       \
-    do {                                                                                                          \
-        if (lds_mode == 2)                                                                                        \
-            PT_LAUNCH_EXTEND1(S, 2);                                                                              \
-        else if (lds_mode == 1)                                                                                   \
-            PT_LAUNCH_EXTEND1(S, 1);                                                                              \
-        else                                                                                                      \
-            PT_LAUNCH_EXTEND1(S, 0);                                                                              \
-    } while (0)
-    if (stack_entries <= 16)
-        PT_LAUNCH_EXTEND(16);
-    else if (stack_entries <= 32)
-        PT_LAUNCH_EXTEND(32);
+    if (lds_mode == 2)
+        PT_LAUNCH_EXTEND1(2);
+    else if (lds_mode == 3)
+        PT_LAUNCH_EXTEND1(3);
+    else if (lds_mode == 1)
+        PT_LAUNCH_EXTEND1(1);
     else
-        PT_LAUNCH_EXTEND(64);
+        PT_LAUNCH_EXTEND1(0);
 #undef PT_LAUNCH_EXTEND2
 #undef PT_LAUNCH_EXTEND1
-#undef PT_LAUNCH_EXTEND
 }
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,

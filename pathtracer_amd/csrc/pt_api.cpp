@@ -364,7 +364,7 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
     r->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
     r->bvh_depth = bvh.depth;
     r->sah_cost = bvh.sah_cost;
-    r->stack_entries = bvh.depth <= 16 ? 16 : (bvh.depth <= 32 ? 32 : 64);
+    r->stack_entries = std::max<uint32_t>(4, (bvh.depth + 3u) & ~3u);  // LDS stack: one entry per inner level, in fours
 
     std::vector<pt::ShadeTriangle> shade(T);
     for (uint32_t t = 0; t < T; ++t) {
@@ -984,7 +984,7 @@ int pt_bvh_inspect(const pt_scene_desc *sc, pt_bvh_info *info)
     info->n_triangles = T;
     info->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
     info->depth = bvh.depth;
-    info->stack_entries = bvh.depth <= 16 ? 16 : (bvh.depth <= 32 ? 32 : 64);
+    info->stack_entries = std::max<uint32_t>(4, (bvh.depth + 3u) & ~3u);
     info->sah_cost = bvh.sah_cost;
 
     // Walk the tree: boxes must enclose everything below them; leaves must

@@ -138,10 +138,11 @@ def test_bvh_extend_equals_linear_scan_of_oracle(pt, ob, name):
 
 
 def test_bvh_extend_on_instanced_lattice(pt, ob):
-    """38 890 triangles, tree depth > 16: exercises the 32-entry stack."""
+    """38 890 triangles, tree depth > 16: a deeper traversal stack, and a node array too large for LDS
+    (the kernel keeps the top of the tree there and reads the rest from global memory)."""
     lat = _scene(pt, "Veggie").instance_lattice(10, 3)
     a = lat.arrays()
-    assert lat.bvh_info()["stack_entries"] >= 32
+    assert lat.bvh_info()["stack_entries"] > 16
     o, d = _secondary_like_rays(a, 20_000, 8)
     eye = default_camera_axes()[0]
     tgt = a["vertices"][np.random.default_rng(2).integers(0, a["vertices"].shape[0], 20_000)]
@@ -157,7 +158,7 @@ def test_bvh_extend_on_instanced_lattice(pt, ob):
     t, ids = r.trace_rays(o, d)
     st = r.stats()
     r.close()
-    assert st["stack_entries"] >= 32
+    assert st["stack_entries"] > 16 and st["n_nodes"] * 64 > 64 * 1024
     assert np.array_equal(ids[ok], oid[ok])
     assert np.array_equal(t.view(np.uint32)[ok], ot.view(np.uint32)[ok])
 
