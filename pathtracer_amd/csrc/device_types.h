@@ -32,6 +32,11 @@ struct DeviceCamera {
     float right[3];
     float height_f;
     uint32_t width, height;
+    // Path slot -> pixel within one iteration (see SlotMap in kernels.hip).
+    uint32_t map_mode;    // 0: slot = pixel; 1: strips of 64 consecutive pixels; 2: tiles of 8 x 8 pixels
+    uint32_t map_units;   // strips or tiles that are permuted (the tail beyond them maps to itself)
+    uint32_t map_stride;  // unit u of the queue is unit (u * map_stride) mod map_units of the image
+    uint32_t tiles_x;     // tiles per image row (mode 2)
 };
 
 }  // namespace pt

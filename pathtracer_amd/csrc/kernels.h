@@ -23,10 +23,14 @@ struct SceneView {
 
 // One path queue: three 16-byte lanes per path.
 //   p0 = (origin.xyz, dir.x)  p1 = (dir.y, dir.z, seed.x, seed.y)  p2 = (throughput.rgb, sample slot)
+// lt: with exactly one light in the scene, the distance at which the ray meets it (frag:363-382), computed by
+// the kernel that creates the ray; < 0 when it does not.  The traversal then starts with that distance as its
+// limit instead of testing the light when the ray finishes.
 struct PathQueue {
     float4 *p0;
     float4 *p1;
     float4 *p2;
+    float *lt;
 };
 
 // The path queues are cut into regions of 2^shift consecutive slots.  A
@@ -65,8 +69,8 @@ struct LaunchShape {
 };
 
 // counts_out: n_regions live counts of bounce 0.
-void launch_raygen(hipStream_t s, LaunchShape g, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
-                   uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift,
+void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, DeviceCamera cam, uint32_t it_first,
+                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift,
                    float4 *samples /* zeroed per path when not null */);
 
 // Where extend puts its results.
@@ -77,6 +81,7 @@ void launch_raygen(hipStream_t s, LaunchShape g, DeviceCamera cam, uint32_t it_f
 //                  the last allowed segment) add nothing; other surface hits are appended per region to
 //                  hit_list as (t, triangle, slot in region, -) and regions.counts_out receives their number.
 struct ExtendOutput {
+    bool light_distance_in_queue;  // q.lt is valid (rays made by raygen / shade in a one-light scene)
     float4 *hit_list;
     float4 *samples;
     unsigned long long *nan_counter;
@@ -100,8 +105,10 @@ void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, floa
                        unsigned long long *shade_totals /* [0] surface hits shaded, [1] 64-lane batches formed */);
 
 // hits -> int32 hit codes / t / directions in pixel order for one iteration.
+// cam: the camera whose raygen made the rays (its slot -> pixel mapping orders the output by pixel); null: rays
+// were packed by the caller, output in slot order.
 void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *results, int32_t *ids,
-                           float *t, float *dirs);
+                           float *t, float *dirs, const DeviceCamera *cam);
 
 void launch_pack_rays(hipStream_t s, LaunchShape g, uint32_t n, const float *origins, const float *dirs, PathQueue q,
                       uint32_t *counts_out, uint32_t region_shift);

@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace pt {
@@ -82,8 +83,48 @@ __device__ __forceinline__ float rng_next(uint32_t &sx, uint32_t &sy)
 
 // ---------------------------------------------------------------- raygen
 
-// frag:866 + frag:306-320.  Path slot i = k * (W*H) + pixel, pixel = y*W + x.
-__global__ void __launch_bounds__(kBlock) k_raygen(DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
+// frag:363-382 for one light: distance along the ray to the light's rectangle,
+// -1 when the ray does not meet it (from behind, beside, or never).
+// Rows evaluated ((m0*x + m1*y) + m2*z) + m3*w, as in test_lights below.
+__device__ __forceinline__ float light_distance(const DeviceLight &L, f3 o, f3 d)
+{
+    const float *m = L.inv;
+    const float lox = ((m[0] * o.x + m[4] * o.y) + m[8] * o.z) + m[12] * 1.f;
+    const float loy = ((m[1] * o.x + m[5] * o.y) + m[9] * o.z) + m[13] * 1.f;
+    const float loz = ((m[2] * o.x + m[6] * o.y) + m[10] * o.z) + m[14] * 1.f;
+    const float ldx = ((m[0] * d.x + m[4] * d.y) + m[8] * d.z) + m[12] * 0.f;
+    const float ldy = ((m[1] * d.x + m[5] * d.y) + m[9] * d.z) + m[13] * 0.f;
+    const float ldz = ((m[2] * d.x + m[6] * d.y) + m[10] * d.z) + m[14] * 0.f;
+    const float dt = -ldz;
+    if (dt < 0.f) return -1.f;
+    const float tl = loz / dt;
+    if (tl < 0.f) return -1.f;
+    const float px = lox + ldx * tl, py = loy + ldy * tl;
+    if (!(fabsf(px) <= 0.5f && fabsf(py) <= 0.5f)) return -1.f;
+    return tl;  // finite and >= 0 here: an infinite or NaN tl fails the rectangle test
+}
+
+// Which pixel a path slot of an iteration renders.  Consecutive slots are
+// grouped into units of 64 pixels that lie together in the image (an 8 x 8 tile
+// when both image sizes are multiples of 8, else 64 pixels of a row), which
+// keeps the rays of a wave coherent; consecutive units of the queue are taken
+// from all over the image (unit u of the queue = unit u * stride mod n of the
+// image, stride near n / golden ratio), so that every region of the queue
+// holds the same mix of empty background and geometry and the persistent waves
+// get equal shares of the work.  The image does not depend on the mapping: a
+// sample is a function of (pixel, iteration) only.
+__device__ __forceinline__ uint32_t pixel_of_slot(const DeviceCamera &cam, uint32_t j)
+{
+    if (cam.map_mode == 0u || (j >> 6) >= cam.map_units) return j;
+    const uint32_t unit = static_cast<uint32_t>((static_cast<unsigned long long>(j >> 6) * cam.map_stride) % cam.map_units);
+    const uint32_t in_unit = j & 63u;
+    if (cam.map_mode == 1u) return (unit << 6) + in_unit;
+    const uint32_t ty = unit / cam.tiles_x, tx = unit - ty * cam.tiles_x;
+    return ((ty << 3) + (in_unit >> 3)) * cam.width + (tx << 3) + (in_unit & 7u);
+}
+
+// frag:866 + frag:306-320.  Path slot i = k * (W*H) + j, j-th slot of iteration k -> pixel_of_slot.
+__global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
                                                     uint32_t n_iterations, PathQueue out, uint32_t *counts_out,
                                                     uint32_t region_shift, float4 *__restrict__ samples)
 {
@@ -99,7 +140,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceCamera cam, uint32_t it
     const f3 H = (right * cam.tan_half_fov) * cam.aspect;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
         const uint32_t k = i / n_pixels;
-        const uint32_t pixel = i - k * n_pixels;
+        const uint32_t pixel = pixel_of_slot(cam, i - k * n_pixels);
         const uint32_t y = pixel / cam.width;
         const uint32_t x = pixel - y * cam.width;
         const uint32_t iteration = it_first + k * it_stride;
@@ -115,7 +156,8 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DeviceCamera cam, uint32_t it
         const f3 d = normalizem(p - eye);
         out.p0[i] = make_float4(eye.x, eye.y, eye.z, d.x);
         out.p1[i] = make_float4(d.y, d.z, __uint_as_float(sx), __uint_as_float(sy));
-        out.p2[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(i));
+        out.p2[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(k * n_pixels + pixel));
+        if (sc.n_lights == 1u) out.lt[i] = light_distance(sc.lights[0], eye, d);
         // Only a path that reaches a light writes its sample; everything else adds zero.
         if (samples) samples[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((i & (region_slots - 1u)) == 0u) counts_out[i >> region_shift] = min(region_slots, total - i);
@@ -295,7 +337,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 // that escapes or sits on the last allowed segment adds nothing -- and appends
 // the remaining surface hits, compacted per region with ballot + prefix rank,
 // to the hit list the shade kernel consumes: (t, triangle, slot in region).
-template <bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER>
+template <bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER, bool USE_LT>
 __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
                                                         float4 *__restrict__ hit_list, float4 *__restrict__ samples,
                                                         unsigned long long *__restrict__ nan_counter, uint32_t last_segment,
@@ -319,6 +361,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
     const uint32_t n_waves = gridDim.x * (kExtBlock / 64);
     unsigned long long my_nodes = 0, my_tris = 0;
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-level diagnostics (COUNT only)
+    const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
 
     // The wave streams through its regions: when the current one has handed out
     // all its rays, idle lanes start on the next one while the last rays of the
@@ -340,6 +383,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
         float ix = 0.f, iy = 0.f, iz = 0.f, cnx = 0.f, cny = 0.f, cnz = 0.f, cfx = 0.f, cfy = 0.f, cfz = 0.f;
         bool negx = false, negy = false, negz = false;
         Hit h{__builtin_inff(), -1};
+        float ltv = -1.f;  // distance to the light when known beforehand, else < 0
         int node = 0, sp = 0;
 
         for (;;) {
@@ -395,7 +439,10 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                         negx = ix < 0.f;
                         negy = iy < 0.f;
                         negz = iz < 0.f;
-                        h.t = __builtin_inff();
+                        // one-light scenes: the light's distance, known since the ray was made, is the limit
+                        // the traversal starts with (a surface beyond the light cannot change the outcome)
+                        ltv = USE_LT ? q.lt[slot] : -1.f;
+                        h.t = ltv >= 0.f ? ltv : __builtin_inff();
                         h.id = -1;
                         node = 0;
                         sp = 0;
@@ -404,8 +451,6 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                     }
                 }
                 if (COUNT) {
-                    dg[6] += 1;
-                    dg[7] += min(n_idle, cur_n - cur_next);
                 }
                 cur_next += n_idle;
             }
@@ -509,7 +554,12 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 hit_t = h.t;
                 hit_code = h.id < 0 ? h.id : (h.id & kIdMask);
                 other = h.id >= 0 && (h.id & kClassBit) != 0;
-                test_lights(sc, o, d, hit_t, hit_code);
+                if (USE_LT) {
+                    // the light wins unless a surface lies strictly in front of it (frag:427: reject if tl > t)
+                    if (ltv >= 0.f && !(ltv > h.t)) hit_code = -2;
+                } else {
+                    test_lights(sc, o, d, hit_t, hit_code);
+                }
                 if (!RENDER) {
                     results[slot] = make_float2(hit_t, __int_as_float(hit_code));
                 } else if (hit_code <= -2) {
@@ -544,8 +594,13 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
     if (COUNT) {
         atomicAdd(tc.nodes_visited, my_nodes);
         atomicAdd(tc.tris_tested, my_tris);
-        if (tc.diag && (tid & 63u) == 0)
-            for (int j = 0; j < 8; ++j) atomicAdd(tc.diag + j, dg[j]);
+        if (tc.diag && (tid & 63u) == 0) {
+            for (int j = 0; j < 6; ++j) atomicAdd(tc.diag + j, dg[j]);
+            // [6] sum over waves of the time each was busy, [7] sum over launches of the longest (100 MHz ticks)
+            const unsigned long long dt = wall_clock64() - t_start;
+            atomicAdd(tc.diag + 6, dt);
+            atomicMax(tc.diag + 7, dt);
+        }
     }
 }
 
@@ -865,14 +920,15 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
     uint32_t k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     uint32_t nxt_r = k < rg.n_regions ? region_of(rg, k) : 0u;
     uint32_t nxt_packed = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
-    for (; k < rg.n_regions; k += n_waves) {
+    while (k < rg.n_regions) {
       const uint32_t r = nxt_r;
       // hits on purely diffuse surfaces from the region's first slot upwards (low half of the count),
       // all others from its last slot downwards (high half).  Full batches of 64 of one kind, then of
       // the other; what is left of both shares one batch when it fits.
       const uint32_t packed = nxt_packed;
-      if (k + n_waves < rg.n_regions) {  // the next region's count is fetched while this one is shaded
-          nxt_r = region_of(rg, k + n_waves);
+      k += n_waves;
+      if (k < rg.n_regions) {  // the next region's count is fetched while this one is shaded
+          nxt_r = region_of(rg, k);
           nxt_packed = rg.counts_in[nxt_r];
       }
       const uint32_t n0 = packed & 0xFFFFu, n1 = packed >> 16;
@@ -964,6 +1020,8 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
             out.p0[dst] = o0;
             out.p1[dst] = o1;
             out.p2[dst] = o2;
+            if (sc.n_lights == 1u)
+                out.lt[dst] = light_distance(sc.lights[0], mk(o0.x, o0.y, o0.z), mk(o0.w, o1.x, o1.y));
         }
         out_n += static_cast<uint32_t>(__popcll(live));
       }
@@ -1024,18 +1082,21 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
 
 // --------------------------------------------------------------- helpers
 
+// slot_is_pixel == 0: slot i holds the ray of pixel pixel_of_slot(i) (rays made by k_raygen).
 __global__ void __launch_bounds__(kBlock) k_unpack_primary(uint32_t n, PathQueue q, const float2 *__restrict__ hits,
-                                                            int32_t *ids, float *t, float *dirs)
+                                                            int32_t *ids, float *t, float *dirs, DeviceCamera cam,
+                                                            uint32_t slot_is_pixel)
 {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const float2 h = hits[i];
-        if (ids) ids[i] = __float_as_int(h.y);
-        if (t) t[i] = h.x;
+        const size_t at = slot_is_pixel ? i : pixel_of_slot(cam, i);
+        if (ids) ids[at] = __float_as_int(h.y);
+        if (t) t[at] = h.x;
         if (dirs) {
             const float4 a = q.p0[i], b = q.p1[i];
-            dirs[3 * static_cast<size_t>(i) + 0] = a.w;
-            dirs[3 * static_cast<size_t>(i) + 1] = b.x;
-            dirs[3 * static_cast<size_t>(i) + 2] = b.y;
+            dirs[3 * at + 0] = a.w;
+            dirs[3 * at + 1] = b.x;
+            dirs[3 * at + 2] = b.y;
         }
     }
 }
@@ -1123,14 +1184,20 @@ uint32_t resident_grid(K kernel, size_t lds_bytes, LaunchShape g, int block = kB
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     const uint32_t resident = g.n_cus * static_cast<uint32_t>(per_cu);
     const uint32_t needed = (g.wave_items + (block / 64) - 1) / (block / 64);
+    if (std::getenv("PT_EVEN_GRID")) {  // tuning experiments only
+        const uint32_t wpb = block / 64, rw = resident * wpb, items = g.wave_items < 1 ? 1 : g.wave_items;
+        const uint32_t turns = (items + rw - 1) / rw, waves = (items + turns - 1) / turns;
+        return (waves + wpb - 1) / wpb;
+    }
     return needed < resident ? (needed < 1 ? 1 : needed) : resident;
 }
 }  // namespace
 
-void launch_raygen(hipStream_t s, LaunchShape g, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
-                   uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift, float4 *samples)
+void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, DeviceCamera cam, uint32_t it_first,
+                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift,
+                   float4 *samples)
 {
-    hipLaunchKernelGGL(k_raygen, dim3(g.blocks), dim3(kBlock), 0, s, cam, it_first, it_stride, n_iterations, out,
+    hipLaunchKernelGGL(k_raygen, dim3(g.blocks), dim3(kBlock), 0, s, scene, cam, it_first, it_stride, n_iterations, out,
                        counts_out, region_shift, samples);
 }
 
@@ -1157,6 +1224,8 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         return;
     }
     const bool counting = tc.nodes_visited != nullptr;
+    static const bool no_lt = std::getenv("PT_NO_LT") != nullptr;  // tuning experiments only
+    const bool use_lt = out.light_distance_in_queue && scene.n_lights == 1u && !no_lt && render;
     // Dynamic LDS: the per-lane stacks, then as much of the scene as a block may hold while four blocks
     // (16 waves) still fit on a CU: all nodes and triangles, else all nodes, else the top of the tree.
     static const size_t budget = [] {
@@ -1179,26 +1248,30 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         n_lds_nodes = static_cast<uint32_t>((budget - stack_bytes) / record);
     }
     const size_t lds_bytes = stack_bytes + n_lds_nodes * record + (lds_mode == 2 ? tri_bytes : 0);
-#define PT_LAUNCH_EXTEND2(C, E, L, R)                                                                              \
+#define PT_LAUNCH_EXTEND2(C, E, L, R, T)                                                                           \
     do {                                                                                                          \
         if (lds_bytes > 64 * 1024)                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_bvh<C, E, L, R>),                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_bvh<C, E, L, R, T>),                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));     \
-        hipLaunchKernelGGL((k_extend_bvh<C, E, L, R>),                                                            \
-                           dim3(resident_grid(k_extend_bvh<C, E, L, R>, lds_bytes, g, kExtBlock)), dim3(kExtBlock), \
-                           lds_bytes, s, scene, regions, q, out.hit_list, out.samples, out.nan_counter, last, tc,  \
-                           n_nodes, refill_at, stack_entries, n_lds_nodes);                                       \
+        hipLaunchKernelGGL((k_extend_bvh<C, E, L, R, T>),                                                         \
+                           dim3(resident_grid(k_extend_bvh<C, E, L, R, T>, lds_bytes, g, kExtBlock)),               \
+                           dim3(kExtBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples,            \
+                           out.nan_counter, last, tc, n_nodes, refill_at, stack_entries, n_lds_nodes);            \
     } while (0)
 #define PT_LAUNCH_EXTEND1(L)                                                                                       \
     do {                                                                                                          \
         if (exact_parallel)                                                                                       \
-            PT_LAUNCH_EXTEND2(false, true, L, false);                                                             \
+            PT_LAUNCH_EXTEND2(false, true, L, false, false);                                                      \
         else if (!render)                                                                                         \
-            PT_LAUNCH_EXTEND2(false, false, L, false);                                                            \
+            PT_LAUNCH_EXTEND2(false, false, L, false, false);                                                     \
+        else if (counting && use_lt)                                                                              \
+            PT_LAUNCH_EXTEND2(true, false, L, true, true);                                                        \
         else if (counting)                                                                                        \
-            PT_LAUNCH_EXTEND2(true, false, L, true);                                                              \
+            PT_LAUNCH_EXTEND2(true, false, L, true, false);                                                       \
+        else if (use_lt)                                                                                          \
+            PT_LAUNCH_EXTEND2(false, false, L, true, true);                                                       \
         else                                                                                                      \
-            PT_LAUNCH_EXTEND2(false, false, L, true);                                                             \
+            PT_LAUNCH_EXTEND2(false, false, L, true, false);                                                      \
     } while (0)
     if (lds_mode == 2)
         PT_LAUNCH_EXTEND1(2);
@@ -1227,9 +1300,10 @@ void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, floa
 }
 
 void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *hits, int32_t *ids,
-                           float *t, float *dirs)
+                           float *t, float *dirs, const DeviceCamera *cam)
 {
-    hipLaunchKernelGGL(k_unpack_primary, dim3(g.blocks), dim3(kBlock), 0, s, n, q, hits, ids, t, dirs);
+    hipLaunchKernelGGL(k_unpack_primary, dim3(g.blocks), dim3(kBlock), 0, s, n, q, hits, ids, t, dirs,
+                       cam ? *cam : DeviceCamera{}, cam ? 0u : 1u);
 }
 
 void launch_pack_rays(hipStream_t s, LaunchShape g, uint32_t n, const float *origins, const float *dirs, PathQueue q,

@@ -111,7 +111,7 @@ struct pt_renderer {
     // path state
     uint32_t width = 0, height = 0, batch_iterations = 1;
     size_t capacity = 0;
-    pt::PathQueue q[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    pt::PathQueue q[2] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
     float4 *d_hits = nullptr;                 // hit list of the render loop; (t, code) results of the readbacks
     float4 *d_samples = nullptr;
     float4 *d_sum = nullptr;
@@ -149,7 +149,8 @@ void free_paths(pt_renderer *r)
         if (r->q[k].p0) (void)hipFree(r->q[k].p0);
         if (r->q[k].p1) (void)hipFree(r->q[k].p1);
         if (r->q[k].p2) (void)hipFree(r->q[k].p2);
-        r->q[k] = pt::PathQueue{nullptr, nullptr, nullptr};
+        if (r->q[k].lt) (void)hipFree(r->q[k].lt);
+        r->q[k] = pt::PathQueue{nullptr, nullptr, nullptr, nullptr};
     }
     if (r->d_hits) (void)hipFree(r->d_hits);
     if (r->d_samples) (void)hipFree(r->d_samples);
@@ -159,6 +160,16 @@ void free_paths(pt_renderer *r)
     r->d_hits = nullptr;
     r->d_samples = nullptr;
     r->d_sum = nullptr;
+}
+
+uint32_t gcd_u32(uint32_t a, uint32_t b)
+{
+    while (b) {
+        uint32_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
 }
 
 int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
@@ -182,6 +193,7 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         PT_HIP(hipMalloc(&r->q[b].p0, r->capacity * sizeof(float4)));
         PT_HIP(hipMalloc(&r->q[b].p1, r->capacity * sizeof(float4)));
         PT_HIP(hipMalloc(&r->q[b].p2, r->capacity * sizeof(float4)));
+        PT_HIP(hipMalloc(&r->q[b].lt, r->capacity * sizeof(float)));
     }
     if (!r->region_shift_fixed) {
         // Region size: large regions amortise the per-region work, small ones balance the persistent waves
@@ -204,18 +216,21 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
     r->cam.width_f = static_cast<float>(width);
     r->cam.height_f = static_cast<float>(height);
     r->cam.aspect = static_cast<float>(width) / static_cast<float>(height);
+    {
+        // Slot -> pixel mapping of the queues (kernels.hip, pixel_of_slot): units of 64 pixels, scattered.
+        const uint32_t n_px = width * height;
+        const bool tiles = (width % 8u == 0u) && (height % 8u == 0u);
+        r->cam.map_mode = std::getenv("PT_NO_SCATTER") ? 0u : (tiles ? 2u : 1u);  // (environment: experiments only)
+        r->cam.map_units = n_px / 64u;
+        r->cam.tiles_x = tiles ? width / 8u : 0u;
+        uint32_t stride = static_cast<uint32_t>(r->cam.map_units * 0.6180339887) | 1u;
+        while (r->cam.map_units > 1u && gcd_u32(stride, r->cam.map_units) != 1u) stride += 2u;
+        r->cam.map_stride = r->cam.map_units > 1u ? stride % r->cam.map_units : 1u;
+        if (r->cam.map_stride == 0u || r->cam.map_units < 2u) r->cam.map_mode = 0u;
+    }
     return PT_OK;
 }
 
-uint32_t gcd_u32(uint32_t a, uint32_t b)
-{
-    while (b) {
-        uint32_t t = a % b;
-        a = b;
-        b = t;
-    }
-    return a;
-}
 
 // Region bookkeeping for a launch over n_items queue slots: wave w visits the
 // regions (k * stride) mod n_regions, k = w, w + n_waves, ...; a stride near
@@ -303,7 +318,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     const pt::LaunchShape g = shape_for(r, n_paths);
     {
         Timed t(r, 0);
-        pt::launch_raygen(r->stream, g, r->cam, it_first, r->world, kb, r->q[0], r->d_counts, r->region_shift, r->d_samples);
+        pt::launch_raygen(r->stream, g, r->view, r->cam, it_first, r->world, kb, r->q[0], r->d_counts, r->region_shift, r->d_samples);
     }
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = r->q[b & 1], &out = r->q[(b + 1) & 1];
@@ -311,7 +326,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
         const int hit_row = static_cast<int>(depth + 1 + b);
         {
             Timed t(r, 1);
-            pt::ExtendOutput eo{r->d_hits, r->d_samples, r->d_counters + 1, true, last, false};
+            pt::ExtendOutput eo{true, r->d_hits, r->d_samples, r->d_counters + 1, true, last, false};
             pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, hit_row), in,
                               eo, tc, r->n_nodes, r->scene_in_lds);
         }
@@ -854,12 +869,12 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
     if (t) PT_TRY(hipMalloc(&d_t, n * sizeof(float)));
     if (dirs) PT_TRY(hipMalloc(&d_dirs, 3 * n * sizeof(float)));
     const pt::LaunchShape g = shape_for(r, n);
-    pt::launch_raygen(r->stream, g, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_shift, nullptr);
+    pt::launch_raygen(r->stream, g, r->view, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_shift, nullptr);
     pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0],
-                      pt::ExtendOutput{r->d_hits, nullptr, nullptr, false, false, r->exact_readbacks},
+                      pt::ExtendOutput{true, r->d_hits, nullptr, nullptr, false, false, r->exact_readbacks},
                       pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
     pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(n), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids, d_t,
-                              d_dirs);
+                              d_dirs, &r->cam);
     PT_TRY(hipGetLastError());
     if (ids) PT_TRY(hipMemcpyAsync(ids, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
     if (t) PT_TRY(hipMemcpyAsync(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
@@ -897,10 +912,10 @@ int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float 
         const pt::LaunchShape g = shape_for(r, c);
         pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], r->d_counts, r->region_shift);
         pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, c, 0, -1), r->q[0],
-                          pt::ExtendOutput{r->d_hits, nullptr, nullptr, false, false, r->exact_readbacks},
+                          pt::ExtendOutput{false, r->d_hits, nullptr, nullptr, false, false, r->exact_readbacks},
                           pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
         pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(c), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids,
-                                  d_t, nullptr);
+                                  d_t, nullptr, nullptr);
         PT_TRY(hipGetLastError());
         if (t) PT_TRY(hipMemcpyAsync(t + off, d_t, c * sizeof(float), hipMemcpyDeviceToHost, r->stream));
         if (ids) PT_TRY(hipMemcpyAsync(ids + off, d_ids, c * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
