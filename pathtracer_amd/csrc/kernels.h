@@ -33,7 +33,7 @@ struct PathQueue {
     float *lt;
 };
 
-// The path queues are cut into regions of 2^shift consecutive slots.  A
+// The path queues are cut into regions of `size` consecutive slots.  A
 // region belongs to exactly one wave for the duration of a kernel, which
 // compacts the survivors of region r into region r of the other queue and
 // writes the region's new live count: no atomics and no ordering between
@@ -47,7 +47,7 @@ struct Regions {
     uint32_t *counts_out;  // may be null (extend does not change counts)
     uint32_t n_regions;
     uint32_t stride;
-    uint32_t shift;        // log2 of the slots per region
+    uint32_t size;         // slots per region (a multiple of 64, at most 32768)
 };
 
 struct TraversalCounters {
@@ -70,7 +70,7 @@ struct LaunchShape {
 
 // counts_out: n_regions live counts of bounce 0.
 void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, DeviceCamera cam, uint32_t it_first,
-                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift,
+                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_size,
                    float4 *samples /* zeroed per path when not null */);
 
 // Where extend puts its results.
@@ -96,6 +96,11 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
                    bool scene_in_lds);
 
 // regions.counts_in = hits per region, regions.counts_out = surviving paths per region.
+// Waves of the traversal kernel that are resident at once for this scene (the occupancy the LDS-resident part
+// of the scene leaves): the host sizes the regions so that each of them gets the same number of regions.
+uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes,
+                               bool scene_in_lds);
+
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
                   const float4 *hit_list, PathQueue out);
 
@@ -111,7 +116,7 @@ void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q
                            float *t, float *dirs, const DeviceCamera *cam);
 
 void launch_pack_rays(hipStream_t s, LaunchShape g, uint32_t n, const float *origins, const float *dirs, PathQueue q,
-                      uint32_t *counts_out, uint32_t region_shift);
+                      uint32_t *counts_out, uint32_t region_size);
 
 void launch_tonemap(hipStream_t s, LaunchShape g, const float4 *sum, uint8_t *rgb, uint32_t width, uint32_t height);
 
@@ -120,3 +125,4 @@ void launch_sample_surface(hipStream_t s, LaunchShape g, uint32_t n, const float
                            float *f_out, uint32_t *flags_out, uint32_t *seeds_out);
 
 }  // namespace pt
+

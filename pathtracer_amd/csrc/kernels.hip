@@ -126,9 +126,8 @@ __device__ __forceinline__ uint32_t pixel_of_slot(const DeviceCamera &cam, uint3
 // frag:866 + frag:306-320.  Path slot i = k * (W*H) + j, j-th slot of iteration k -> pixel_of_slot.
 __global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
                                                     uint32_t n_iterations, PathQueue out, uint32_t *counts_out,
-                                                    uint32_t region_shift, float4 *__restrict__ samples)
+                                                    uint32_t region_slots, float4 *__restrict__ samples)
 {
-    const uint32_t region_slots = 1u << region_shift;
     const uint32_t n_pixels = cam.width * cam.height;
     const uint32_t total = n_pixels * n_iterations;
     const f3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
@@ -160,7 +159,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, DeviceCamera ca
         if (sc.n_lights == 1u) out.lt[i] = light_distance(sc.lights[0], eye, d);
         // Only a path that reaches a light writes its sample; everything else adds zero.
         if (samples) samples[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((i & (region_slots - 1u)) == 0u) counts_out[i >> region_shift] = min(region_slots, total - i);
+        if (i % region_slots == 0u) counts_out[i / region_slots] = min(region_slots, total - i);
     }
 }
 
@@ -229,7 +228,7 @@ __device__ __forceinline__ void test_lights(const SceneView &sc, f3 o, f3 d, flo
 // upwards from the region's first slot, all other surfaces downwards from its
 // last, so that the shade kernel's waves mostly see one kind of material.
 // Ballot + prefix rank per end; n0 / n1 are the wave-uniform counts so far.
-__device__ __forceinline__ void append_hit(float4 *__restrict__ hit_list, uint32_t region_base, uint32_t shift, bool append,
+__device__ __forceinline__ void append_hit(float4 *__restrict__ hit_list, uint32_t region_base, uint32_t size, bool append,
                                            bool other, float4 rec, uint32_t &n0, uint32_t &n1)
 {
     const unsigned long long m0 = __ballot(append && !other), m1 = __ballot(append && other);
@@ -237,7 +236,7 @@ __device__ __forceinline__ void append_hit(float4 *__restrict__ hit_list, uint32
         const unsigned long long m = other ? m1 : m0;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-        const uint32_t at = other ? ((1u << shift) - 1u - (n1 + rank)) : (n0 + rank);
+        const uint32_t at = other ? (size - 1u - (n1 + rank)) : (n0 + rank);
         hit_list[region_base + at] = rec;
     }
     n0 += static_cast<uint32_t>(__popcll(m0));
@@ -256,7 +255,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
     for (uint32_t k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); k < rg.n_regions; k += n_waves) {
       const uint32_t r = region_of(rg, k);
       const uint32_t n = rg.counts_in[r];
-      const uint32_t region_base = r << rg.shift;
+      const uint32_t region_base = r * rg.size;
       uint32_t hit_n0 = 0, hit_n1 = 0;
       for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
         bool append = false;
@@ -289,7 +288,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
             }
         }
         if (RENDER)
-            append_hit(hit_list, region_base, rg.shift, append, other,
+            append_hit(hit_list, region_base, rg.size, append, other,
                        make_float4(t, __int_as_float(code), __uint_as_float(j0 + lane), 0.f), hit_n0, hit_n1);
       }
       if (RENDER && lane == 0) rg.counts_out[r] = hit_n0 | (hit_n1 << 16);
@@ -397,7 +396,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                     prv_r = cur_r, prv_base = cur_base, prv_h0 = cur_h0, prv_h1 = cur_h1, prv_valid = cur_valid;
                     cur_r = nxt_r;
                     cur_n = nxt_n;
-                    cur_base = cur_r << rg.shift;
+                    cur_base = cur_r * rg.size;
                     cur_next = 0;
                     cur_h0 = cur_h1 = 0;
                     cur_valid = true;
@@ -579,10 +578,10 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
             }
             if (RENDER) {
                 const bool for_prev = gen != cur_gen;
-                append_hit(hit_list, cur_base, rg.shift, append && !for_prev, other,
+                append_hit(hit_list, cur_base, rg.size, append && !for_prev, other,
                            make_float4(hit_t, __int_as_float(hit_code), __uint_as_float(slot - cur_base), 0.f), cur_h0, cur_h1);
                 if (__ballot(append && for_prev) != 0ull)
-                    append_hit(hit_list, prv_base, rg.shift, append && for_prev, other,
+                    append_hit(hit_list, prv_base, rg.size, append && for_prev, other,
                                make_float4(hit_t, __int_as_float(hit_code), __uint_as_float(slot - prv_base), 0.f), prv_h0, prv_h1);
             }
         }
@@ -935,8 +934,8 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
       const uint32_t full0 = n0 >> 6, full1 = n1 >> 6, rem0 = n0 & 63u, rem1 = n1 & 63u;
       const bool merged = rem0 + rem1 <= 64u;
       const uint32_t batches = full0 + full1 + (merged ? ((rem0 + rem1) != 0u ? 1u : 0u) : 2u);
-      const uint32_t region_base = r << rg.shift;
-      const uint32_t last_slot = (1u << rg.shift) - 1u;
+      const uint32_t region_base = r * rg.size;
+      const uint32_t last_slot = rg.size - 1u;
       uint32_t out_n = 0;  // wave-uniform: survivors written to this region so far
       for (uint32_t bt = 0; bt < batches; ++bt) {
         // which hit this lane takes: index from the front (take0) or from the back (take1) of the list
@@ -1103,11 +1102,10 @@ __global__ void __launch_bounds__(kBlock) k_unpack_primary(uint32_t n, PathQueue
 
 __global__ void __launch_bounds__(kBlock) k_pack_rays(uint32_t n, const float *__restrict__ origins,
                                                        const float *__restrict__ dirs, PathQueue q, uint32_t *counts_out,
-                                                       uint32_t region_shift)
+                                                       uint32_t region_slots)
 {
-    const uint32_t region_slots = 1u << region_shift;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        if ((i & (region_slots - 1u)) == 0u) counts_out[i >> region_shift] = min(region_slots, n - i);
+        if (i % region_slots == 0u) counts_out[i / region_slots] = min(region_slots, n - i);
         const size_t k = 3 * static_cast<size_t>(i);
         q.p0[i] = make_float4(origins[k], origins[k + 1], origins[k + 2], dirs[k]);
         q.p1[i] = make_float4(dirs[k + 1], dirs[k + 2], 0.f, 0.f);
@@ -1194,11 +1192,70 @@ uint32_t resident_grid(K kernel, size_t lds_bytes, LaunchShape g, int block = kB
 }  // namespace
 
 void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, DeviceCamera cam, uint32_t it_first,
-                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_shift,
+                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_size,
                    float4 *samples)
 {
     hipLaunchKernelGGL(k_raygen, dim3(g.blocks), dim3(kBlock), 0, s, scene, cam, it_first, it_stride, n_iterations, out,
-                       counts_out, region_shift, samples);
+                       counts_out, region_size, samples);
+}
+
+namespace {
+// Dynamic LDS of the traversal kernel: the per-lane stacks, then as much of the scene as a block may hold
+// while four blocks (16 waves) still fit on a CU: all nodes and triangles (mode 2), else all nodes (3), else
+// the top of the tree (1), else nothing (0).
+struct LdsPlan {
+    int mode;
+    uint32_t n_lds_nodes;
+    size_t bytes;
+};
+LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds)
+{
+    static const size_t budget = [] {
+        const char *e = std::getenv("PT_LDS_BUDGET_KB");  // tuning experiments only
+        return static_cast<size_t>(e ? std::atoi(e) : 40) * 1024;
+    }();
+    const size_t stack_bytes = static_cast<size_t>(stack_entries) * kExtBlock * sizeof(StackT);
+    const size_t record = 16 * PT_LDS_STRIDE;
+    const size_t node_bytes = static_cast<size_t>(n_nodes) * record, tri_bytes = static_cast<size_t>(scene.n_triangles) * record;
+    LdsPlan p{0, 0, 0};
+    if (scene_in_lds && stack_bytes + node_bytes + tri_bytes <= budget) {
+        p.mode = 2;
+        p.n_lds_nodes = n_nodes;
+    } else if (scene_in_lds && stack_bytes + node_bytes <= budget) {
+        p.mode = 3;
+        p.n_lds_nodes = n_nodes;
+    } else if (scene_in_lds && stack_bytes + 64 * record <= budget) {
+        p.mode = 1;
+        p.n_lds_nodes = static_cast<uint32_t>((budget - stack_bytes) / record);
+    }
+    p.bytes = stack_bytes + p.n_lds_nodes * record + (p.mode == 2 ? tri_bytes : 0);
+    return p;
+}
+}  // namespace
+
+uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes,
+                               bool scene_in_lds)
+{
+    const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds);
+    const bool lt = scene.n_lights == 1u;
+    int per_cu = 0;
+    hipError_t rc = hipErrorUnknown;
+#define PT_OCC(L)                                                                                                   \
+    rc = lt ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_bvh<false, false, L, true, true>,    \
+                                                           kExtBlock, plan.bytes)                                  \
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_bvh<false, false, L, true, false>,   \
+                                                           kExtBlock, plan.bytes)
+    if (plan.mode == 2)
+        PT_OCC(2);
+    else if (plan.mode == 3)
+        PT_OCC(3);
+    else if (plan.mode == 1)
+        PT_OCC(1);
+    else
+        PT_OCC(0);
+#undef PT_OCC
+    if (rc != hipSuccess || per_cu < 1) per_cu = 1;
+    return n_cus * static_cast<uint32_t>(per_cu) * (kExtBlock / 64);
 }
 
 void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
@@ -1226,28 +1283,10 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     const bool counting = tc.nodes_visited != nullptr;
     static const bool no_lt = std::getenv("PT_NO_LT") != nullptr;  // tuning experiments only
     const bool use_lt = out.light_distance_in_queue && scene.n_lights == 1u && !no_lt && render;
-    // Dynamic LDS: the per-lane stacks, then as much of the scene as a block may hold while four blocks
-    // (16 waves) still fit on a CU: all nodes and triangles, else all nodes, else the top of the tree.
-    static const size_t budget = [] {
-        const char *e = std::getenv("PT_LDS_BUDGET_KB");  // tuning experiments only
-        return static_cast<size_t>(e ? std::atoi(e) : 40) * 1024;
-    }();
-    const size_t stack_bytes = static_cast<size_t>(stack_entries) * kExtBlock * sizeof(StackT);
-    const size_t record = 16 * PT_LDS_STRIDE;
-    const size_t node_bytes = static_cast<size_t>(n_nodes) * record, tri_bytes = static_cast<size_t>(scene.n_triangles) * record;
-    int lds_mode = 0;
-    uint32_t n_lds_nodes = 0;
-    if (scene_in_lds && stack_bytes + node_bytes + tri_bytes <= budget) {
-        lds_mode = 2;
-        n_lds_nodes = n_nodes;
-    } else if (scene_in_lds && stack_bytes + node_bytes <= budget) {
-        lds_mode = 3;
-        n_lds_nodes = n_nodes;
-    } else if (scene_in_lds && stack_bytes + 64 * record <= budget) {
-        lds_mode = 1;
-        n_lds_nodes = static_cast<uint32_t>((budget - stack_bytes) / record);
-    }
-    const size_t lds_bytes = stack_bytes + n_lds_nodes * record + (lds_mode == 2 ? tri_bytes : 0);
+    const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds);
+    const int lds_mode = plan.mode;
+    const uint32_t n_lds_nodes = plan.n_lds_nodes;
+    const size_t lds_bytes = plan.bytes;
 #define PT_LAUNCH_EXTEND2(C, E, L, R, T)                                                                           \
     do {                                                                                                          \
         if (lds_bytes > 64 * 1024)                                                                                \
@@ -1307,9 +1346,9 @@ void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q
 }
 
 void launch_pack_rays(hipStream_t s, LaunchShape g, uint32_t n, const float *origins, const float *dirs, PathQueue q,
-                      uint32_t *counts_out, uint32_t region_shift)
+                      uint32_t *counts_out, uint32_t region_size)
 {
-    hipLaunchKernelGGL(k_pack_rays, dim3(g.blocks), dim3(kBlock), 0, s, n, origins, dirs, q, counts_out, region_shift);
+    hipLaunchKernelGGL(k_pack_rays, dim3(g.blocks), dim3(kBlock), 0, s, n, origins, dirs, q, counts_out, region_size);
 }
 
 void launch_tonemap(hipStream_t s, LaunchShape g, const float4 *sum, uint8_t *rgb, uint32_t width, uint32_t height)

@@ -117,8 +117,8 @@ struct pt_renderer {
     float4 *d_sum = nullptr;
     uint32_t *d_counts = nullptr;             // (max_depth + 1) rows of region_pitch live counts, one row per bounce
     uint32_t region_pitch = 0;                // regions the queues hold at full capacity
-    uint32_t region_shift = 10;               // log2(slots per region), chosen from the batch size
-    bool region_shift_fixed = false;          // set through the environment (experiments)
+    uint32_t region_size = 1024;              // slots per region, chosen from the batch size and the resident waves
+    uint32_t region_size_env = 0;             // set through the environment (experiments)
     bool scene_in_lds = true;                 // extend keeps nodes (and triangles) in LDS when they fit
     unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics [12] hits shaded [13] shade batches
 
@@ -195,19 +195,25 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         PT_HIP(hipMalloc(&r->q[b].p2, r->capacity * sizeof(float4)));
         PT_HIP(hipMalloc(&r->q[b].lt, r->capacity * sizeof(float)));
     }
-    if (!r->region_shift_fixed) {
-        // Region size: large regions amortise the per-region work, small ones balance the persistent waves
-        // (16 per CU).  Measured best at about three regions per wave; 256 ... 2048 slots.
-        const size_t per_wave = r->capacity / (size_t(3) * 16 * std::max<uint32_t>(1, r->n_cus));
-        uint32_t shift = 8;
-        while (shift < 11 && (size_t(2) << shift) <= per_wave) ++shift;
-        r->region_shift = shift;
+    {
+        // Region size.  The traversal kernel runs `waves` persistent waves; every wave should get the same
+        // whole number m of regions (a wave with one region more than the others sets the kernel's run time),
+        // regions of about 2048 slots amortise the per-region work best, and the two-ended hit list packs its
+        // counts into 16 bits each.  size = capacity / (waves * m), rounded up to a multiple of 64.
+        const uint32_t waves = r->cfg.use_bvh
+                                   ? pt::extend_resident_waves(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds)
+                                   : r->n_cus * 32u;
+        size_t m = std::max<size_t>(1, (r->capacity + size_t(waves) * 1024) / (size_t(waves) * 2048));
+        size_t size = (r->capacity + waves * m - 1) / (waves * m);
+        size = std::max<size_t>(256, (size + 63) & ~size_t(63));
+        while (size > 32768) size = ((size / 2) + 63) & ~size_t(63);
+        r->region_size = r->region_size_env ? r->region_size_env : static_cast<uint32_t>(size);
     }
-    r->region_pitch = static_cast<uint32_t>((r->capacity + (size_t(1) << r->region_shift) - 1) >> r->region_shift);
+    r->region_pitch = static_cast<uint32_t>((r->capacity + r->region_size - 1) / r->region_size);
     // rows 0..depth: live rays per region and bounce; rows depth+1..2*depth: surface hits per region and bounce
     PT_HIP(hipMalloc(&r->d_counts, static_cast<size_t>(2 * r->cfg.max_depth + 1) * r->region_pitch * sizeof(uint32_t)));
     // whole regions: the hit list of a region is filled from both of its ends
-    PT_HIP(hipMalloc(&r->d_hits, (static_cast<size_t>(r->region_pitch) << r->region_shift) * sizeof(float4)));
+    PT_HIP(hipMalloc(&r->d_hits, static_cast<size_t>(r->region_pitch) * r->region_size * sizeof(float4)));
     PT_HIP(hipMalloc(&r->d_samples, r->capacity * sizeof(float4)));
     PT_HIP(hipMalloc(&r->d_sum, n_pixels * sizeof(float4)));
     PT_HIP(hipMemsetAsync(r->d_sum, 0, n_pixels * sizeof(float4), r->stream));
@@ -239,8 +245,8 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
 pt::Regions regions_for(const pt_renderer *r, size_t n_items, uint32_t row_in, int row_out)
 {
     pt::Regions g;
-    g.shift = r->region_shift;
-    g.n_regions = static_cast<uint32_t>(std::max<size_t>(1, (n_items + (size_t(1) << g.shift) - 1) >> g.shift));
+    g.size = r->region_size;
+    g.n_regions = static_cast<uint32_t>(std::max<size_t>(1, (n_items + g.size - 1) / g.size));
     uint32_t stride = static_cast<uint32_t>(g.n_regions * 0.6180339887) | 1u;
     while (gcd_u32(stride, g.n_regions) != 1u) stride += 2u;
     g.stride = g.n_regions == 1 ? 1u : stride % g.n_regions;
@@ -254,7 +260,7 @@ pt::LaunchShape shape_for(const pt_renderer *r, size_t work_items)
 {
     const size_t blocks_needed = (work_items + 255) / 256;
     const size_t cap = static_cast<size_t>(r->n_cus) * 8;
-    const size_t regions = (work_items + (size_t(1) << r->region_shift) - 1) >> r->region_shift;
+    const size_t regions = (work_items + r->region_size - 1) / r->region_size;
     return pt::LaunchShape{static_cast<uint32_t>(std::max<size_t>(1, std::min(blocks_needed, cap))), r->n_cus,
                            static_cast<uint32_t>(std::max<size_t>(1, regions))};
 }
@@ -318,7 +324,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     const pt::LaunchShape g = shape_for(r, n_paths);
     {
         Timed t(r, 0);
-        pt::launch_raygen(r->stream, g, r->view, r->cam, it_first, r->world, kb, r->q[0], r->d_counts, r->region_shift, r->d_samples);
+        pt::launch_raygen(r->stream, g, r->view, r->cam, it_first, r->world, kb, r->q[0], r->d_counts, r->region_size, r->d_samples);
     }
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = r->q[b & 1], &out = r->q[(b + 1) & 1];
@@ -683,12 +689,9 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     pt_renderer *r = new pt_renderer();
     r->cfg = cfg;
     r->device = device;
-    if (const char *e = std::getenv("PT_REGION_SHIFT")) {  // tuning experiments only
+    if (const char *e = std::getenv("PT_REGION_SIZE")) {  // tuning experiments only
         int v = std::atoi(e);
-        if (v >= 6 && v <= 15) {
-            r->region_shift = static_cast<uint32_t>(v);
-            r->region_shift_fixed = true;
-        }
+        if (v >= 64 && v <= 32768 && v % 64 == 0) r->region_size_env = static_cast<uint32_t>(v);
     }
     if (const char *e = std::getenv("PT_SCENE_LDS")) r->scene_in_lds = std::atoi(e) != 0;  // tuning experiments only
     hipDeviceProp_t prop;
@@ -869,7 +872,7 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
     if (t) PT_TRY(hipMalloc(&d_t, n * sizeof(float)));
     if (dirs) PT_TRY(hipMalloc(&d_dirs, 3 * n * sizeof(float)));
     const pt::LaunchShape g = shape_for(r, n);
-    pt::launch_raygen(r->stream, g, r->view, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_shift, nullptr);
+    pt::launch_raygen(r->stream, g, r->view, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_size, nullptr);
     pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0],
                       pt::ExtendOutput{true, r->d_hits, nullptr, nullptr, false, false, r->exact_readbacks},
                       pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
@@ -910,7 +913,7 @@ int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float 
         PT_TRY(hipMemcpyAsync(d_o, origins + 3 * off, 3 * c * sizeof(float), hipMemcpyHostToDevice, r->stream));
         PT_TRY(hipMemcpyAsync(d_d, dirs + 3 * off, 3 * c * sizeof(float), hipMemcpyHostToDevice, r->stream));
         const pt::LaunchShape g = shape_for(r, c);
-        pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], r->d_counts, r->region_shift);
+        pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], r->d_counts, r->region_size);
         pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, c, 0, -1), r->q[0],
                           pt::ExtendOutput{false, r->d_hits, nullptr, nullptr, false, false, r->exact_readbacks},
                           pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
