@@ -283,3 +283,57 @@ def test_image_equivalence_bvh_vs_scan(pt):
         out.append(r.read_sum())
         r.close()
     assert np.array_equal(out[0], out[1])
+
+
+# ------------------------------------------------------------------ lights
+
+def _box_with_lights(pt, lights):
+    a = dict(scene_arrays("Box"))
+    a["lights"] = np.asarray(lights, np.float32).reshape(-1, 20)
+    return a
+
+
+def test_two_lights_and_no_light_use_the_general_light_test(pt, ob):
+    """With one light the distance to it travels with the ray and limits the
+    traversal; any other number of lights goes through the reference's loop over
+    lights (frag:418-430) when the ray finishes.  Both must give the reference's
+    hit codes (light k = -(2 + k)) and identical images from the BVH kernel and
+    the linear-scan kernel."""
+    first = scene_arrays("Box")["lights"].reshape(-1, 20)[0]
+    second = pt.make_light((2.0, 1.0, 0.5), (-0.6, 0.4, 0.9), (0.3, 0.8, 0.0), (0.7, 0.5, 1.0))
+    for lights in ([first, second], [second, first], np.zeros((0, 20), np.float32)):
+        a = _box_with_lights(pt, lights)
+        sc = ob.OracleScene(a)
+        oid, ot, _ = ob.primary(sc, ob.make_camera(*default_camera_axes(), 160, 120), 3)
+        sums = []
+        for use_bvh in (True, False):
+            r = pt.Renderer(pt.Scene.from_arrays(**a), pt.Camera(resolution=(160, 120)), max_depth=6, use_bvh=use_bvh)
+            ids, t, _ = r.read_hit_ids(3, True)
+            assert np.array_equal(ids, oid)
+            assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+            r.draw(8)
+            sums.append(r.read_sum())
+            r.close()
+        assert np.array_equal(sums[0], sums[1])
+        n_lights = len(lights)
+        if n_lights == 2:
+            assert (oid == -2).any() and (oid == -3).any()
+            assert sums[0][..., :3].max() > 0
+        else:
+            assert not sums[0][..., :3].any()
+
+
+def test_one_light_limit_equals_general_light_test(pt):
+    """The same one-light scene rendered through the BVH kernel (light distance
+    as the traversal limit) and through the scan kernel (light tested when the
+    ray finishes): identical sums, at a size whose queue mapping is by tiles and
+    at one whose mapping is by strips with a ragged tail."""
+    for w, h in [(128, 64), (131, 67)]:
+        out = []
+        for use_bvh in (True, False):
+            r = _renderer(pt, "Veggie", w, h, max_depth=8, use_bvh=use_bvh)
+            r.draw(6)
+            out.append(r.read_sum())
+            r.close()
+        assert np.array_equal(out[0], out[1])
+        assert np.all(out[0][..., 3] == 6)
