@@ -6,6 +6,9 @@ The reference is single-GPU (one GL context); what makes this partition exact
 is that a sample depends only on (pixel, iteration index)
 (pathtracer.frag.glsl:866) and that accumulation here is a float SUM rather
 than the reference's 8-bit running average (pathtracer.frag.glsl:900-904).
+
+Load order: import torch before pathtracer_amd in such a process (torch's wheel
+brings its own HIP runtime, and the first one loaded is the one both use).
 """
 from __future__ import annotations
 
@@ -37,6 +40,11 @@ def sum_buffer_as_tensor(renderer, device):
     tensor that aliases it."""
     import torch
 
+    if not torch.cuda.is_available():
+        # torch's wheel carries its own HIP runtime; whichever of torch and this library is loaded first decides
+        # which runtime the process uses, and torch only finds the GPUs with its own.
+        raise RuntimeError("torch sees no GPU: in a multi-GPU process import torch (and set the device) before "
+                           "pathtracer_amd, as bench.py does")
     arr = _DeviceArray(renderer.sum_device_ptr(), (renderer.height, renderer.width, 4))
     return torch.as_tensor(arr, device=device)
 
