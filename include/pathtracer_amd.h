@@ -153,6 +153,15 @@ int pt_render(pt_renderer *r, uint32_t n_iterations);
 int pt_set_partition(pt_renderer *r, uint32_t rank, uint32_t world);
 int pt_synchronize(pt_renderer *r);
 
+/* Checkpoint / resume of a progressive render.  The reference's render state is its accumulation texture and
+ * iteration counter (renderer.h:21-29, renderer.cpp:132-133); here: the float sum buffer, the number of
+ * iterations this renderer has done, and the partition they belong to.  The file also records the image size,
+ * maximum depth, camera basis and a checksum of the scene arrays; pt_load_state refuses a file that does not
+ * match the renderer it is loaded into (PT_ERR_STATE).  After a load, pt_render continues with the next
+ * iteration index, and the final sums equal those of an uninterrupted render bit for bit. */
+int pt_save_state(pt_renderer *r, const char *path);
+int pt_load_state(pt_renderer *r, const char *path);
+
 /* Readbacks (the reference shows the image in a window; none of these has a
  * counterpart there).  All synchronise first. */
 /* Sum of samples: width*height*4 floats, rgb = radiance sum, a = sample count. */

@@ -154,6 +154,8 @@ _SIGNATURES = {
     "pt_render": (C.c_int, [_vp, C.c_uint32]),
     "pt_set_partition": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "pt_synchronize": (C.c_int, [_vp]),
+    "pt_save_state": (C.c_int, [_vp, C.c_char_p]),
+    "pt_load_state": (C.c_int, [_vp, C.c_char_p]),
     "pt_read_sum": (C.c_int, [_vp, _f32p]),
     "pt_read_radiance": (C.c_int, [_vp, _f32p]),
     "pt_read_tonemapped": (C.c_int, [_vp, _u8p]),
@@ -412,6 +414,14 @@ class Renderer:
     # ---- multi-GPU partition, sync, readbacks
     def set_partition(self, rank: int, world: int) -> None:
         _check(_lib.pt_set_partition(self._h, rank, world))
+
+    def save_state(self, path: str) -> None:
+        """Checkpoint: sum buffer + iteration counter (the reference's render state, renderer.h:21-29)."""
+        _check(_lib.pt_save_state(self._h, os.fsencode(path)))
+
+    def load_state(self, path: str) -> None:
+        """Resume from a checkpoint written for the same scene, camera, depth, size and partition."""
+        _check(_lib.pt_load_state(self._h, os.fsencode(path)))
 
     def synchronize(self) -> None:
         _check(_lib.pt_synchronize(self._h))

@@ -3,14 +3,21 @@
 // but the image goes to a file instead of a window.
 //
 //   pt_render [--scene assets/TEST.obj] [--mtl-root assets/] [--width 1280] [--height 720]
-//             [--spp 64] [--depth 10] [--fov 19.5] [--eye x y z] [--focus x y z] [--scan]
-//             [--out image.ppm] [--pfm radiance.pfm]
+//             [--spp 64] [--depth 10] [--fov 19.5] [--eye x y z] [--focus x y z]
+//             [--orbit dx dy] [--pan dx dy] [--zoom s]      camera moves of main.cpp:75-112, applied in order
+//             [--light r g b  px py pz  rx ry rz  sx sy sz]  repeatable; replaces the default light
+//             [--no-light]
+//             [--resume state.bin] [--save-state state.bin] [--checkpoint-every n]
+//             [--scan] [--out image.ppm] [--pfm radiance.pfm]
+// --spp is the total: after --resume only the missing samples are rendered.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <string>
+#include <vector>
 
 #include "renderer.h"
 
@@ -46,7 +53,15 @@ int main(int argc, char **argv)
     uint32_t width = 1280, height = 720, spp = 64, depth = 10;
     float fov = 19.5f;
     pt::Vec3 eye = pt::make3(0.f, 1.5f, 15.f), focus = pt::make3(0.f, -0.25f, 0.f);
-    bool scan = false;
+    bool scan = false, no_light = false;
+    std::string resume, save_state;
+    uint32_t checkpoint_every = 0;
+    std::vector<pt::Scene::Light> lights;
+    struct Move {
+        char kind;
+        float a, b;
+    };
+    std::vector<Move> moves;
     for (int i = 1; i < argc; ++i) {
         auto next = [&](int k = 1) -> const char * {
             if (i + k >= argc) {
@@ -65,6 +80,23 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--out")) out = next(), ++i;
         else if (!std::strcmp(argv[i], "--pfm")) pfm = next(), ++i;
         else if (!std::strcmp(argv[i], "--scan")) scan = true;
+        else if (!std::strcmp(argv[i], "--no-light")) no_light = true;
+        else if (!std::strcmp(argv[i], "--resume")) resume = next(), ++i;
+        else if (!std::strcmp(argv[i], "--save-state")) save_state = next(), ++i;
+        else if (!std::strcmp(argv[i], "--checkpoint-every")) checkpoint_every = std::atoi(next()), ++i;
+        else if (!std::strcmp(argv[i], "--light")) {
+            float v[12];
+            for (int k = 0; k < 12; ++k) v[k] = static_cast<float>(std::atof(next(k + 1)));
+            lights.emplace_back(pt::make3(v[0], v[1], v[2]), pt::make3(v[3], v[4], v[5]), pt::make3(v[6], v[7], v[8]),
+                                pt::make3(v[9], v[10], v[11]));
+            i += 12;
+        } else if (!std::strcmp(argv[i], "--orbit") || !std::strcmp(argv[i], "--pan")) {
+            moves.push_back(Move{argv[i][2], static_cast<float>(std::atof(next(1))), static_cast<float>(std::atof(next(2)))});
+            i += 2;
+        } else if (!std::strcmp(argv[i], "--zoom")) {
+            moves.push_back(Move{'z', static_cast<float>(std::atof(next())), 0.f});
+            ++i;
+        }
         else if (!std::strcmp(argv[i], "--eye")) {
             eye = pt::make3(std::atof(next(1)), std::atof(next(2)), std::atof(next(3)));
             i += 3;
@@ -84,17 +116,41 @@ int main(int argc, char **argv)
             std::fprintf(stderr, "no triangles loaded from %s\n", scene_path.c_str());
             return 1;
         }
-        scene.setDefaultLight();
+        if (no_light || !lights.empty()) {
+            scene.m_lights = lights;
+            scene.m_lightCount[0] = static_cast<uint32_t>(lights.size());
+        } else {
+            scene.setDefaultLight();
+        }
         pt::Camera camera(eye, focus, width, height);
+        for (const Move &m : moves) {
+            if (m.kind == 'o') camera.orbit(m.a, m.b);
+            else if (m.kind == 'p') camera.pan(m.a, m.b);
+            else camera.zoom(m.a);
+        }
         pt::Renderer renderer(&scene, &camera, depth, fov, !scan);
+        uint32_t done = 0;
+        if (!resume.empty()) {
+            renderer.loadState(resume);
+            done = static_cast<uint32_t>(renderer.stats().iterations);
+            std::printf("resumed %s at %u spp\n", resume.c_str(), done);
+        }
+        const uint32_t resumed_at = done;
         auto t0 = std::chrono::steady_clock::now();
-        renderer.draw(spp);
+        while (done < spp) {
+            const uint32_t n = checkpoint_every ? std::min(checkpoint_every, spp - done) : spp - done;
+            renderer.draw(n);
+            done += n;
+            if (checkpoint_every && !save_state.empty()) renderer.saveState(save_state);
+        }
         renderer.synchronize();
+        if (!save_state.empty()) renderer.saveState(save_state);
         double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         pt_stats st = renderer.stats();
+        const double new_paths = static_cast<double>(done - resumed_at) * width * height;  // segments count this run only
         std::printf("%zu triangles, %u BVH nodes (depth %u), %ux%u, %u spp, depth %u: %.3f s, %.1f Mpaths/s, %.2f segments/path\n",
-                    scene.m_indices.size(), st.n_nodes, st.bvh_depth, width, height, spp, depth, secs,
-                    static_cast<double>(st.paths) / secs / 1e6, static_cast<double>(st.segments) / static_cast<double>(st.paths));
+                    scene.m_indices.size(), st.n_nodes, st.bvh_depth, width, height, done, depth, secs,
+                    new_paths / secs / 1e6, new_paths > 0 ? static_cast<double>(st.segments) / new_paths : 0.0);
         if (!write_ppm(out, renderer.tonemapped(), width, height)) {
             std::fprintf(stderr, "cannot write %s\n", out.c_str());
             return 1;

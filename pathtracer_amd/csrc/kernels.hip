@@ -43,10 +43,10 @@ using StackT = PT_STACK_T;
 #ifndef PT_EXTEND_WAVES
 #define PT_EXTEND_WAVES 1
 #endif
-// Measured on MI355X (Box / Veggie at 1080p): shade is fastest at 5 waves per SIMD
+// Measured on MI355X (Box / Veggie at 1080p): shade is fastest at 4-5 waves per SIMD
 // (96 VGPRs, 24 bytes of scratch); extend is fastest with its natural 74 VGPRs.
 #ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 5
+#define PT_SHADE_WAVES 4
 #endif
 constexpr float kPi = 3.14159265358979323f;     // frag:3
 constexpr float kInvPi = 0.31830988618379067f;  // frag:4

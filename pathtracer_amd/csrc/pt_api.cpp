@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
@@ -119,6 +120,7 @@ struct pt_renderer {
     uint32_t region_pitch = 0;                // regions the queues hold at full capacity
     uint32_t region_size = 1024;              // slots per region, chosen from the batch size and the resident waves
     uint32_t region_size_env = 0;             // set through the environment (experiments)
+    uint64_t scene_hash = 0;                  // FNV-1a over the scene arrays (checkpoint compatibility)
     bool scene_in_lds = true;                 // extend keeps nodes (and triangles) in LDS when they fit
     unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics [12] hits shaded [13] shade batches
 
@@ -357,9 +359,29 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     return PT_OK;
 }
 
+uint64_t fnv1a(uint64_t h, const void *data, size_t bytes)
+{
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < bytes; ++i) {
+        h ^= p[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
 int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
 {
     const uint32_t T = sc->n_triangles;
+    {
+        uint64_t h = 1469598103934665603ull;
+        h = fnv1a(h, sc->vertices, static_cast<size_t>(sc->n_vertices) * 12);
+        h = fnv1a(h, sc->indices, static_cast<size_t>(T) * 16);
+        h = fnv1a(h, sc->vertex_data, static_cast<size_t>(T) * 3 * 24);
+        h = fnv1a(h, sc->lights, static_cast<size_t>(sc->n_lights) * 80);
+        h = fnv1a(h, sc->materials, static_cast<size_t>(sc->n_materials) * 32);
+        h = fnv1a(h, sc->material_map, static_cast<size_t>(T) * 4);
+        r->scene_hash = h;
+    }
     std::vector<uint32_t> ids(static_cast<size_t>(T) * 3);
     for (uint32_t t = 0; t < T; ++t)
         for (int k = 0; k < 3; ++k) {
@@ -795,6 +817,87 @@ int pt_render(pt_renderer *r, uint32_t n_iterations)
         if (rc != PT_OK) return rc;
         left -= kb;
     }
+    return PT_OK;
+}
+
+namespace {
+struct StateHeader {
+    char magic[8];  // "PTAMDST1"
+    uint32_t width, height, max_depth, rank, world, reserved;
+    uint64_t local_iterations, paths, scene_hash;
+    float fov_y_degrees;
+    float eye[3], forward[3], up[3], right[3];
+};
+}  // namespace
+
+int pt_save_state(pt_renderer *r, const char *path)
+{
+    PT_REQUIRE(r && path, "pt_save_state: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    const size_t n = static_cast<size_t>(r->width) * r->height * 4;
+    std::vector<float> sum(n);
+    int rc = pt_read_sum(r, sum.data());
+    if (rc != PT_OK) return rc;
+    StateHeader h;
+    std::memset(&h, 0, sizeof(h));
+    std::memcpy(h.magic, "PTAMDST1", 8);
+    h.width = r->width;
+    h.height = r->height;
+    h.max_depth = r->cfg.max_depth;
+    h.rank = r->rank;
+    h.world = r->world;
+    h.local_iterations = r->local_iterations;
+    h.paths = r->paths;
+    h.scene_hash = r->scene_hash;
+    h.fov_y_degrees = r->cfg.fov_y_degrees;
+    for (int k = 0; k < 3; ++k) {
+        h.eye[k] = r->cam.eye[k];
+        h.forward[k] = r->cam.forward[k];
+        h.up[k] = r->cam.up[k];
+        h.right[k] = r->cam.right[k];
+    }
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return fail(PT_ERR_IO, std::string("pt_save_state: cannot write ") + tmp);
+    const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(sum.data(), sizeof(float), n, f) == n;
+    const bool closed = std::fclose(f) == 0;
+    if (!ok || !closed || std::rename(tmp.c_str(), path) != 0) {
+        std::remove(tmp.c_str());
+        return fail(PT_ERR_IO, std::string("pt_save_state: writing ") + path + " failed");
+    }
+    return PT_OK;
+}
+
+int pt_load_state(pt_renderer *r, const char *path)
+{
+    PT_REQUIRE(r && path, "pt_load_state: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(PT_ERR_IO, std::string("pt_load_state: cannot open ") + path);
+    StateHeader h;
+    const size_t n = static_cast<size_t>(r->width) * r->height * 4;
+    std::vector<float> sum(n);
+    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "PTAMDST1", 8) == 0;
+    const bool fits = ok && h.width == r->width && h.height == r->height;
+    ok = fits && std::fread(sum.data(), sizeof(float), n, f) == n && std::fgetc(f) == EOF;
+    std::fclose(f);
+    if (!fits) return fail(PT_ERR_STATE, std::string("pt_load_state: ") + path + " is not a state file of this image size");
+    if (!ok) return fail(PT_ERR_IO, std::string("pt_load_state: ") + path + " is truncated or has trailing data");
+    bool same = h.max_depth == r->cfg.max_depth && h.scene_hash == r->scene_hash && h.rank == r->rank &&
+                h.world == r->world && h.fov_y_degrees == r->cfg.fov_y_degrees;
+    for (int k = 0; k < 3; ++k)
+        same = same && h.eye[k] == r->cam.eye[k] && h.forward[k] == r->cam.forward[k] && h.up[k] == r->cam.up[k] &&
+               h.right[k] == r->cam.right[k];
+    if (!same)
+        return fail(PT_ERR_STATE, "pt_load_state: the file was written for another scene, camera, depth or partition");
+    const uint64_t next = h.rank + h.local_iterations * static_cast<uint64_t>(h.world);
+    if (next > 0xFFFFFFFEull) return fail(PT_ERR_STATE, "pt_load_state: iteration counter out of range");
+    int rc = reset_accumulation(r);
+    if (rc != PT_OK) return rc;
+    PT_HIP(hipMemcpyAsync(r->d_sum, sum.data(), n * sizeof(float), hipMemcpyHostToDevice, r->stream));
+    PT_HIP(hipStreamSynchronize(r->stream));
+    r->local_iterations = h.local_iterations;
+    r->paths = h.paths;
     return PT_OK;
 }
 

@@ -65,6 +65,11 @@ public:
         check(pt_set_camera(m_handle, &m_camera->m_eye.x, &m_camera->m_forward.x, &m_camera->m_up.x, &m_camera->m_right.x));
     }
 
+    // Checkpoint / resume: the sum buffer and the iteration counter (the reference's render state,
+    // renderer.h:21-29), refused on load if scene, camera, depth, size or partition differ.
+    void saveState(const std::string &path) { check(pt_save_state(m_handle, path.c_str())); }
+    void loadState(const std::string &path) { check(pt_load_state(m_handle, path.c_str())); }
+
     void synchronize() { check(pt_synchronize(m_handle)); }
     std::vector<float> radiance()
     {

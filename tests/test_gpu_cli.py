@@ -1,0 +1,87 @@
+"""The headless command-line renderer (stand-in for main.cpp): scene file, lights and camera from the
+command line, image files out, checkpoint and resume."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "pathtracer_amd", "pt_render")
+
+ROOM = """mtllib room.mtl
+v -2 -2 -2
+v 2 -2 -2
+v 2 2 -2
+v -2 2 -2
+v -2 -2 2
+v 2 -2 2
+v 2 2 2
+v -2 2 2
+usemtl white
+f 1 2 3 4
+f 1 5 6 2
+f 4 3 7 8
+usemtl red
+f 1 4 8 5
+usemtl mirror
+f 2 6 7 3
+"""
+MTL = """newmtl white
+Kd 0.8 0.8 0.8
+Ns 0
+newmtl red
+Kd 0.7 0.1 0.1
+Ns 0
+newmtl mirror
+Kd 0.9 0.9 0.9
+Pr 0.1
+Pm 1.0
+"""
+
+
+def _read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = map(int, f.readline().split())
+        assert float(f.readline()) < 0
+        return np.frombuffer(f.read(), "<f4").reshape(h, w, 3)
+
+
+def _run(args, cwd):
+    out = subprocess.run([EXE, *args], cwd=cwd, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return out.stdout
+
+
+def test_cli_lights_camera_checkpoint_resume(tmp_path):
+    if not os.path.exists(EXE):
+        pytest.fail("pathtracer_amd/pt_render is not built")
+    (tmp_path / "room.obj").write_text(ROOM)
+    (tmp_path / "room.mtl").write_text(MTL)
+    common = ["--scene", "room.obj", "--mtl-root", "./", "--width", "96", "--height", "64", "--depth", "5",
+              "--orbit", "0.1", "0.05", "--zoom", "1.5",
+              "--light", "6", "5", "4", "0", "1.9", "0", "1.57", "0", "0", "1.5", "1.5", "1",
+              "--light", "1", "2", "3", "-1.9", "0", "0", "0", "1.57", "0", "1", "1", "1"]
+    log = _run(common + ["--spp", "12", "--out", "a.ppm", "--pfm", "a.pfm"], tmp_path)
+    assert "10 triangles" in log and "12 spp" in log
+    a = _read_pfm(tmp_path / "a.pfm")
+    assert a.shape == (64, 96, 3) and np.isfinite(a).all() and a.max() > 0.5  # the lights are seen
+    with open(tmp_path / "a.ppm", "rb") as f:
+        assert f.readline() == b"P6\n" and f.readline() == b"96 64\n"
+
+    _run(common + ["--spp", "5", "--save-state", "s.bin", "--out", "b0.ppm"], tmp_path)
+    log = _run(common + ["--spp", "12", "--resume", "s.bin", "--checkpoint-every", "4", "--save-state", "s.bin",
+                         "--out", "b.ppm", "--pfm", "b.pfm"], tmp_path)
+    assert "resumed s.bin at 5 spp" in log
+    assert np.array_equal(_read_pfm(tmp_path / "b.pfm"), a)
+    assert (tmp_path / "a.ppm").read_bytes() == (tmp_path / "b.ppm").read_bytes()
+
+    dark = _run(["--scene", "room.obj", "--mtl-root", "./", "--width", "32", "--height", "32", "--spp", "2", "--no-light",
+                 "--pfm", "d.pfm", "--out", "d.ppm"], tmp_path)
+    assert "2 spp" in dark and not _read_pfm(tmp_path / "d.pfm").any()
+    bad = subprocess.run([EXE, "--scene", "room.obj", "--mtl-root", "./", "--width", "32", "--height", "32", "--spp", "2",
+                          "--resume", "s.bin"], cwd=tmp_path, capture_output=True, text=True, timeout=240)
+    assert bad.returncode != 0 and "pt_load_state" in bad.stderr

@@ -176,3 +176,68 @@ def test_full_size_properties_1080p(pt):
     assert 2.0 < st["segments"] / st["paths"] < 4.5  # 16:9 frames more background than 1:1
     mean = a[..., :3].mean(axis=(0, 1)) / 6
     assert 0.02 < mean.min() and mean.max() < 0.12
+
+
+def test_checkpoint_and_resume(pt, tmp_path):
+    """State = sum buffer + iteration counter (the reference's accumulation texture and m_iterationCount,
+    renderer.h:21-29): 5 + 7 iterations through a file equal 12 in one go, bit for bit; a file written for
+    another camera, depth, size, partition or scene is refused."""
+    path = str(tmp_path / "state.bin")
+    straight = _renderer(pt, "Box", 96, 64, max_depth=6)
+    straight.draw(12)
+    ref = straight.read_sum()
+    straight.close()
+
+    a = _renderer(pt, "Box", 96, 64, max_depth=6)
+    a.draw(5)
+    a.save_state(path)
+    a.close()
+    b = _renderer(pt, "Box", 96, 64, max_depth=6)
+    b.draw(3)  # overwritten by the load
+    b.load_state(path)
+    assert b.stats()["iterations"] == 5
+    b.draw(7)
+    assert np.array_equal(b.read_sum(), ref)
+    assert b.stats()["iterations"] == 12 and b.stats()["paths"] == 12 * 96 * 64
+    b.close()
+
+    # partitioned renderers keep their own files
+    p1 = _renderer(pt, "Box", 96, 64, max_depth=6)
+    p1.set_partition(1, 2)
+    p1.draw(3)
+    part = str(tmp_path / "rank1.bin")
+    p1.save_state(part)
+    p1.draw(3)
+    want = p1.read_sum()
+    p1.load_state(part)
+    p1.draw(3)
+    assert np.array_equal(p1.read_sum(), want)
+    with pytest.raises(pt.PtError):
+        p1.load_state(path)  # written by rank 0 of 1
+    p1.close()
+
+    for kw, size in [(dict(max_depth=7), (96, 64)), (dict(max_depth=6), (64, 96))]:
+        c = _renderer(pt, "Box", *size, **kw)
+        with pytest.raises(pt.PtError):
+            c.load_state(path)
+        c.close()
+    c = _renderer(pt, "Box", 96, 64, max_depth=6)
+    c.camera.orbit(0.2, 0.0)
+    c.update_camera()
+    with pytest.raises(pt.PtError):
+        c.load_state(path)
+    c.close()
+    c = _renderer(pt, "Veggie", 96, 64, max_depth=6)
+    with pytest.raises(pt.PtError):
+        c.load_state(path)
+    with pytest.raises(pt.PtError):
+        c.load_state(str(tmp_path / "missing.bin"))
+    with open(path, "rb") as f:
+        blob = f.read()
+    with open(path, "wb") as f:
+        f.write(blob[:-100])
+    c.close()
+    d = _renderer(pt, "Box", 96, 64, max_depth=6)
+    with pytest.raises(pt.PtError):
+        d.load_state(path)  # truncated
+    d.close()
