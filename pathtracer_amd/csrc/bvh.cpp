@@ -1,10 +1,12 @@
 #include "bvh.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 namespace pt {
 
@@ -66,12 +68,24 @@ struct TmpNode {
     uint32_t first = 0, count = 0;  // leaf range in the ordered primitive array
 };
 
+// A subtree handed to a worker thread: the primitive range, its level, and the
+// node of the top tree that stands for it until the worker's nodes are spliced in.
+struct Job {
+    uint32_t begin, end, level;
+    int32_t placeholder;
+};
+
 struct Builder {
     std::vector<Prim> prims;
     std::vector<TmpNode> tmp;
     bool median_only = false;
 
-    int32_t build(uint32_t begin, uint32_t end, uint32_t level = 0)
+    // Builds the subtree over prims[begin, end) into `out` and returns its node.
+    // With `jobs`, subtrees of at most job_size primitives are not built but
+    // recorded (their node stays an empty placeholder).  Ranges of different
+    // subtrees are disjoint, so workers may partition them concurrently.
+    int32_t build(uint32_t begin, uint32_t end, uint32_t level, std::vector<TmpNode> &tmp, std::vector<Job> *jobs,
+                  uint32_t job_size)
     {
         TmpNode node;
         node.box.reset();
@@ -87,6 +101,10 @@ struct Builder {
         if (n <= 1u || (n <= kLeafMax && (median_only || level >= 48))) {
             tmp[self].first = begin;
             tmp[self].count = n;
+            return self;
+        }
+        if (jobs && n <= job_size && n > 4u * kLeafMax) {
+            jobs->push_back(Job{begin, end, level, self});
             return self;
         }
 
@@ -176,11 +194,52 @@ struct Builder {
                                             (a.centroid[axis] == b.centroid[axis] && a.id < b.id);
                                  });
         }
-        int32_t l = build(begin, mid, level + 1);
-        int32_t r = build(mid, end, level + 1);
+        int32_t l = build(begin, mid, level + 1, tmp, jobs, job_size);
+        int32_t r = build(mid, end, level + 1, tmp, jobs, job_size);
         tmp[self].left = l;
         tmp[self].right = r;
         return self;
+    }
+
+    // The whole tree into this->tmp; returns the root.  The top of the tree is
+    // built on the calling thread, the subtrees below it on worker threads, and
+    // their nodes are appended in subtree order, so the result does not depend
+    // on the number of threads or their timing.
+    int32_t build_all()
+    {
+        const uint32_t n = static_cast<uint32_t>(prims.size());
+        unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        if (const char *e = std::getenv("PT_BVH_THREADS")) hw = static_cast<unsigned>(std::max(1, std::atoi(e)));
+        if (n < (1u << 16) || hw < 2) return build(0, n, 0, tmp, nullptr, 0);
+        std::vector<Job> jobs;
+        const int32_t root = build(0, n, 0, tmp, &jobs, std::max<uint32_t>(1024, n / (8 * hw)));
+        std::vector<std::vector<TmpNode>> parts(jobs.size());
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t j = next.fetch_add(1); j < jobs.size(); j = next.fetch_add(1)) {
+                parts[j].reserve(2 * static_cast<size_t>(jobs[j].end - jobs[j].begin) / std::max(1u, kLeafMax / 2) + 16);
+                build(jobs[j].begin, jobs[j].end, jobs[j].level, parts[j], nullptr, 0);  // its root is parts[j][0]
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < hw; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            // node i >= 1 of the part becomes node offset + i - 1; node 0 replaces the placeholder
+            const int32_t offset = static_cast<int32_t>(tmp.size());
+            auto remap = [offset](TmpNode nd) {
+                if (nd.left >= 0) {
+                    nd.left += offset - 1;
+                    nd.right += offset - 1;
+                }
+                return nd;
+            };
+            tmp[jobs[j].placeholder] = remap(parts[j][0]);
+            for (size_t i = 1; i < parts[j].size(); ++i) tmp.push_back(remap(parts[j][i]));
+            std::vector<TmpNode>().swap(parts[j]);
+        }
+        return root;
     }
 };
 
@@ -282,7 +341,7 @@ void build_bvh(const float *vertices, const uint32_t *ids, uint32_t n_triangles,
         b.tmp.reserve(static_cast<size_t>(n_triangles) + 16);
         b.median_only = (attempt == 1);
         out->nodes.clear();
-        int32_t root = b.build(0, n_triangles);
+        int32_t root = b.build_all();
         int32_t code;
         if (b.tmp[root].left < 0) {
             // A scene of <= 4 triangles: wrap the single leaf in a root whose
