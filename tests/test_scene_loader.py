@@ -234,3 +234,20 @@ def test_lattice_instancing(pt):
     info = lat.bvh_info()
     assert info["n_triangles"] == a["indices"].shape[0] and info["max_leaf_size"] <= 4
     assert info["depth"] <= info["stack_entries"]
+
+
+def test_bvh_build_is_the_same_on_one_thread_and_on_many(pt, monkeypatch):
+    """Above 65 536 triangles the subtrees below the top of the tree are built on worker threads and
+    spliced in subtree order: the tree must not depend on the number of threads."""
+    from conftest import scene_arrays
+
+    lat = pt.Scene.from_arrays(**scene_arrays("Veggie")).instance_lattice(10, 5)
+    assert lat.n_triangles == 10 + 1440 * 125
+    infos = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("PT_BVH_THREADS", threads)
+        infos.append(lat.bvh_info())
+    for i in infos[1:]:
+        for key in ("n_nodes", "n_leaves", "depth", "max_leaf_size", "stack_entries", "n_triangles"):
+            assert i[key] == infos[0][key], key
+        assert abs(i["sah_cost"] - infos[0]["sah_cost"]) <= 1e-9 * infos[0]["sah_cost"]
