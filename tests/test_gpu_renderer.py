@@ -157,7 +157,7 @@ def test_scene_without_materials_or_lights(pt):
 
 
 def test_full_size_properties_1080p(pt):
-    """BASELINE size: hit buffer equals the reference's; every pixel gets its
+    """Benchmark size (1920x1080): hit buffer equals the reference's; every pixel gets its
     samples; two renders agree bit for bit; light pixels converge to radiance 4
     at depth 1."""
     r = _renderer(pt, "Box", 1920, 1080, max_depth=8)

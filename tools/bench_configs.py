@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-GPU throughput of every BASELINE configuration (bounded sample counts).
+"""One-GPU throughput of every benchmark configuration (bounded sample counts).
 
     python tools/bench_configs.py [--out gpurun_out/configs.json] [--only NAME]
 

@@ -3,7 +3,7 @@
 # over a short bench.py run.  Results land in gpurun_out/prof/<tag>/.
 # usage: tools/profile_gpu.sh TAG [bench args...]
 set -u
-TAG=${1:-r01}; shift || true
+TAG=${1:-profile}; shift || true
 export TMPDIR=/tmp
 OUT=gpurun_out/prof/$TAG
 mkdir -p "$OUT"
