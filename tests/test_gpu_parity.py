@@ -68,6 +68,20 @@ def test_primary_hit_buffer_bit_exact_vs_reference_1080p(pt, name):
     assert np.array_equal(ids, fx)
 
 
+@pytest.mark.parametrize("name", ["Box_Transmission", "Box_TransmissionSphere", "Box_Anisotropic", "AnisotropicTest"])
+def test_primary_hit_buffer_bit_exact_vs_oracle_1080p(pt, ob, name):
+    """The other benchmark scenes at the benchmark size, against the oracle (which the 256x256 and the
+    Box / Veggie 1920x1080 fixtures pin to the reference): codes, t bits and direction bits."""
+    sc = ob.OracleScene(scene_arrays(name))
+    oid, ot, od = ob.primary(sc, ob.make_camera(*default_camera_axes(), 1920, 1080), 0)
+    r = _renderer(pt, name, 1920, 1080)
+    ids, t, dirs = r.read_hit_ids(0, True, True)
+    r.close()
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(dirs.view(np.uint32), od.view(np.uint32))
+
+
 @pytest.mark.parametrize("w,h,it", [(256, 256, 7), (192, 108, 3)])
 def test_primary_other_iteration_and_aspect(pt, w, h, it):
     fx = hit_fixture("Box", w, h, it)
@@ -159,6 +173,34 @@ def test_bvh_extend_on_instanced_lattice(pt, ob):
     st = r.stats()
     r.close()
     assert st["stack_entries"] > 16 and st["n_nodes"] * 64 > 64 * 1024
+    assert np.array_equal(ids[ok], oid[ok])
+    assert np.array_equal(t.view(np.uint32)[ok], ot.view(np.uint32)[ok])
+
+
+def test_bvh_extend_on_the_ten_million_triangle_scene(pt, ob):
+    """The BVH-stress configuration (Veggie instanced on a 19^3 lattice, 9 876 970 triangles): about a
+    hundred rays through the 5.5 M-node tree (top of the tree in LDS, the rest from memory) against the
+    oracle's linear scan over all triangles, bit for bit."""
+    lat = _scene(pt, "Veggie").instance_lattice(10, 19)
+    a = lat.arrays()
+    assert a["indices"].shape[0] == 9_876_970
+    o, d = _secondary_like_rays(a, 60, 21)
+    eye = default_camera_axes()[0]
+    tgt = a["vertices"][np.random.default_rng(5).integers(0, a["vertices"].shape[0], 36)]
+    d2 = (tgt - eye).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    o = np.concatenate([o, np.tile(eye, (36, 1))]).astype(np.float32)
+    d = np.concatenate([d, d2]).astype(np.float32)
+    osc = ob.OracleScene(a)
+    ot, oid = ob.trace(osc, o, d)
+    ok = ~ob.poisoned(osc, o, d)
+    assert ok[12:].all()
+    r = pt.Renderer(lat, pt.Camera(resolution=(64, 64)))
+    t, ids = r.trace_rays(o, d)
+    st = r.stats()
+    r.close()
+    assert st["n_triangles"] == 9_876_970 and st["bvh_depth"] <= st["stack_entries"]
+    assert (oid[ok] >= 0).sum() > 40
     assert np.array_equal(ids[ok], oid[ok])
     assert np.array_equal(t.view(np.uint32)[ok], ot.view(np.uint32)[ok])
 
