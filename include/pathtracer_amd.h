@@ -65,6 +65,12 @@ typedef struct {
     uint32_t iterations_per_batch; /* samples per pixel in flight at once; 0 = auto     */
     uint32_t profile;              /* bit 0: time every launch with HIP events; bit 1:
                                       count BVH nodes / triangle tests (both slower)    */
+    uint32_t emulate_rgba8;        /* 1: beside the float sum, keep the reference's own
+                                      accumulator: an 8-bit RGBA texel per pixel updated as
+                                      (accum*it + sample)/(it+1) and re-quantised every
+                                      iteration (frag:900-904, renderer.cpp:21,25), NaN
+                                      samples and all.  Single renderer only (the running
+                                      average is not a sum and cannot be partitioned).   */
 } pt_config;
 
 typedef struct {
@@ -171,6 +177,9 @@ int pt_read_radiance(pt_renderer *r, float *rgba_host);
 /* post.frag:11-15 (Reinhard then gamma 1/2.2) on the mean, as 8-bit RGB,
  * row 0 = TOP row (image-file order). */
 int pt_read_tonemapped(pt_renderer *r, uint8_t *rgb_host);
+/* The emulated 8-bit accumulation texture (pt_config.emulate_rgba8): width*height*4 bytes, row 0 = bottom
+ * row like the texture the reference's shader reads back (frag:900), before post.frag. */
+int pt_read_rgba8(pt_renderer *r, uint8_t *rgba_host);
 /* Primary-ray hit codes of iteration `iteration` for every pixel. t_host and
  * dirs_host (3 floats per pixel) may be NULL. Does not touch the accumulation. */
 int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids_host, float *t_host, float *dirs_host);

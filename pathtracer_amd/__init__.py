@@ -66,6 +66,7 @@ class Config(C.Structure):
         ("use_bvh", C.c_uint32),
         ("iterations_per_batch", C.c_uint32),
         ("profile", C.c_uint32),
+        ("emulate_rgba8", C.c_uint32),
     ]
 
 
@@ -154,6 +155,7 @@ _SIGNATURES = {
     "pt_render": (C.c_int, [_vp, C.c_uint32]),
     "pt_set_partition": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "pt_synchronize": (C.c_int, [_vp]),
+    "pt_read_rgba8": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
     "pt_save_state": (C.c_int, [_vp, C.c_char_p]),
     "pt_load_state": (C.c_int, [_vp, C.c_char_p]),
     "pt_read_sum": (C.c_int, [_vp, _f32p]),
@@ -364,7 +366,7 @@ class Renderer:
 
     def __init__(self, scene: Scene, camera: Optional[Camera] = None, *, max_depth: int = 10,
                  fov_y_degrees: float = 19.5, device: int = -1, use_bvh: bool = True,
-                 iterations_per_batch: int = 0, profile: int = 0):
+                 iterations_per_batch: int = 0, profile: int = 0, emulate_rgba8: bool = False):
         self.scene = scene
         self.camera = camera if camera is not None else Camera()
         w, h = self.camera.resolution
@@ -377,6 +379,7 @@ class Renderer:
         cfg.use_bvh = 1 if use_bvh else 0
         cfg.iterations_per_batch = iterations_per_batch
         cfg.profile = int(profile)  # bit 0: per-launch HIP-event timing; bit 1: traversal counters
+        cfg.emulate_rgba8 = 1 if emulate_rgba8 else 0
         self.config = cfg
         self._h = _vp()
         d = scene.desc()
@@ -434,6 +437,12 @@ class Renderer:
     def read_radiance(self) -> np.ndarray:
         out = np.zeros((self.height, self.width, 4), np.float32)
         _check(_lib.pt_read_radiance(self._h, _ptr(out, _f32p)))
+        return out
+
+    def read_rgba8(self) -> np.ndarray:
+        """The emulated 8-bit accumulation texture (emulate_rgba8=True), H x W x 4, row 0 = bottom row."""
+        out = np.zeros((self.height, self.width, 4), np.uint8)
+        _check(_lib.pt_read_rgba8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
     def read_tonemapped(self) -> np.ndarray:

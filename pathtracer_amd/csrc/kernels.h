@@ -102,12 +102,14 @@ uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t 
                                bool scene_in_lds);
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
-                  const float4 *hit_list, PathQueue out);
+                  const float4 *hit_list, PathQueue out, float4 *samples /* receives the NaN sample of a path whose throughput went non-finite */);
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
                        uint32_t pitch, unsigned long long *segments_total,
-                       unsigned long long *shade_totals /* [0] surface hits shaded, [1] 64-lane batches formed */);
+                       unsigned long long *shade_totals /* [0] surface hits shaded, [1] 64-lane batches formed */,
+                       unsigned long long *nan_counter, uint8_t *rgba8 /* may be null */, uint32_t it_first,
+                       uint32_t it_stride);
 
 // hits -> int32 hit codes / t / directions in pixel order for one iteration.
 // cam: the camera whose raygen made the rays (its slot -> pixel mapping orders the output by pixel); null: rays

@@ -277,11 +277,8 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
             } else if (code <= -2) {
                 const float4 c = q.p2[i];
                 const float *rad = sc.lights[-(code + 2)].radiance;
-                f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
-                if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) {
-                    L = mk(0.f, 0.f, 0.f);
-                    atomicAdd(nan_counter, 1ull);
-                }
+                const f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
+                // a non-finite sample is left to the accumulate kernel (which drops and counts it)
                 samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, 1.f);
             } else {
                 append = code >= 0 && last_segment == 0u;
@@ -565,11 +562,8 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                     // passCol = attenuation * intensity (frag:878-882, :901)
                     const float4 c = q.p2[slot];
                     const float *rad = sc.lights[-(hit_code + 2)].radiance;
-                    f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
-                    if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) {
-                        L = mk(0.f, 0.f, 0.f);
-                        atomicAdd(nan_counter, 1ull);
-                    }
+                    const f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
+                    // a non-finite sample is left to the accumulate kernel (which drops and counts it)
                     samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, 1.f);
                 } else {
                     append = hit_code >= 0 && last_segment == 0u;
@@ -912,7 +906,8 @@ __device__ __forceinline__ Material load_material(const SceneView &sc, uint32_t 
 // here (pdf <= 0, a lobe that returned without a direction, zero throughput)
 // simply is not written: its sample slot already holds zero.
 __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, Regions rg, PathQueue in,
-                                                   const float4 *__restrict__ hit_list, PathQueue out)
+                                                   const float4 *__restrict__ hit_list, PathQueue out,
+                                                   float4 *__restrict__ samples)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
@@ -1000,6 +995,15 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
                         att = mk(att.x / r.pdf, att.y / r.pdf, att.z / r.pdf);
                         // A path whose throughput is exactly zero can only ever add zero.
                         if (att.x == 0.f && att.y == 0.f && att.z == 0.f) dead = true;
+                        // A throughput that has gone NaN / inf in all channels stays so: whatever the path
+                        // meets later, the reference's sample is attenuation * intensity = non-finite
+                        // (frag:901; NaN * 0 for a path that never reaches a light).  The path ends here
+                        // with that sample; the accumulate kernel counts it and adds zero to the float image.
+                        if (!isfinite(att.x) && !isfinite(att.y) && !isfinite(att.z)) {
+                            dead = true;
+                            const float nan = __builtin_nanf("");
+                            samples[__float_as_uint(c.w)] = make_float4(nan, nan, nan, 1.f);
+                        }
                     }
                 }
                 if (!dead) {
@@ -1030,6 +1034,14 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
 
 // ------------------------------------------------------------ accumulate
 
+// GL's float -> UNORM8 store: clamp to [0,1], round(x * 255); NaN -> 0.
+__device__ __forceinline__ unsigned char unorm8(float x)
+{
+    if (!(x > 0.f)) return 0;
+    if (x >= 1.f) return 255;
+    return static_cast<unsigned char>(static_cast<int>(x * 255.f + 0.5f));
+}
+
 // sum[pixel] += each of the batch's samples of that pixel, in iteration order
 // (so the image does not depend on how many iterations share a batch).
 __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ sum,
@@ -1037,7 +1049,9 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
                                                         const uint32_t *__restrict__ counts, uint32_t n_rows,
                                                         uint32_t n_regions, uint32_t pitch,
                                                         unsigned long long *__restrict__ segments_total,
-                                                        unsigned long long *__restrict__ shade_totals)
+                                                        unsigned long long *__restrict__ shade_totals,
+                                                        unsigned long long *__restrict__ nan_counter,
+                                                        uint8_t *__restrict__ rgba8, uint32_t it_first, uint32_t it_stride)
 {
     {
         // surface hits shaded in this batch and the 64-lane batches the shade kernel formed of them
@@ -1066,17 +1080,38 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
         if ((threadIdx.x & 63u) == 0 && s != 0) atomicAdd(segments_total, s);
     }
+    unsigned long long dropped = 0;
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pixels; p += gridDim.x * kBlock) {
         float4 acc = sum[p];
+        uchar4 tex = rgba8 ? reinterpret_cast<uchar4 *>(rgba8)[p] : make_uchar4(0, 0, 0, 0);
         for (uint32_t k = 0; k < n_iterations; ++k) {
             const float4 s = samples[static_cast<size_t>(k) * n_pixels + p];
-            acc.x += s.x;
-            acc.y += s.y;
-            acc.z += s.z;
+            if (isfinite(s.x) && isfinite(s.y) && isfinite(s.z)) {
+                acc.x += s.x;
+                acc.y += s.y;
+                acc.z += s.z;
+            } else {
+                ++dropped;  // the float image counts a non-finite sample as zero
+            }
             acc.w += 1.f;
+            if (rgba8) {
+                // frag:900-904 on an 8-bit UNORM texel: col = (accumCol * it + passCol) / (it + 1), then the
+                // store clamps to [0,1] and rounds to 8 bits (NaN becomes 0).
+                const float fi = static_cast<float>(it_first + k * it_stride), fi1 = static_cast<float>(it_first + k * it_stride + 1u);
+                const float cx = ((static_cast<float>(tex.x) / 255.f) * fi + s.x) / fi1;
+                const float cy = ((static_cast<float>(tex.y) / 255.f) * fi + s.y) / fi1;
+                const float cz = ((static_cast<float>(tex.z) / 255.f) * fi + s.z) / fi1;
+                tex.x = unorm8(cx);
+                tex.y = unorm8(cy);
+                tex.z = unorm8(cz);
+                tex.w = 255;
+            }
         }
         sum[p] = acc;
+        if (rgba8) reinterpret_cast<uchar4 *>(rgba8)[p] = tex;
     }
+    for (int off = 32; off > 0; off >>= 1) dropped += __shfl_down(dropped, off);
+    if ((threadIdx.x & 63u) == 0 && dropped != 0) atomicAdd(nan_counter, dropped);
 }
 
 // --------------------------------------------------------------- helpers
@@ -1325,17 +1360,20 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
 }
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
-                  const float4 *hit_list, PathQueue out)
+                  const float4 *hit_list, PathQueue out, float4 *samples)
 {
-    hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g)), dim3(kBlock), 0, s, scene, regions, in, hit_list, out);
+    hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g)), dim3(kBlock), 0, s, scene, regions, in, hit_list, out,
+                       samples);
 }
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
-                       uint32_t pitch, unsigned long long *segments_total, unsigned long long *shade_totals)
+                       uint32_t pitch, unsigned long long *segments_total, unsigned long long *shade_totals,
+                       unsigned long long *nan_counter, uint8_t *rgba8, uint32_t it_first, uint32_t it_stride)
 {
     hipLaunchKernelGGL(k_accumulate, dim3(g.blocks), dim3(kBlock), 0, s, samples, sum, n_pixels, n_iterations, counts,
-                       n_rows, n_regions, pitch, segments_total, shade_totals);
+                       n_rows, n_regions, pitch, segments_total, shade_totals, nan_counter,
+                       rgba8, it_first, it_stride);
 }
 
 void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *hits, int32_t *ids,

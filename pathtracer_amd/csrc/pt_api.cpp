@@ -121,6 +121,7 @@ struct pt_renderer {
     uint32_t region_size = 1024;              // slots per region, chosen from the batch size and the resident waves
     uint32_t region_size_env = 0;             // set through the environment (experiments)
     uint64_t scene_hash = 0;                  // FNV-1a over the scene arrays (checkpoint compatibility)
+    uint8_t *d_rgba8 = nullptr;               // emulated 8-bit accumulation texture (cfg.emulate_rgba8)
     bool scene_in_lds = true;                 // extend keeps nodes (and triangles) in LDS when they fit
     unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics [12] hits shaded [13] shade batches
 
@@ -157,6 +158,8 @@ void free_paths(pt_renderer *r)
     if (r->d_hits) (void)hipFree(r->d_hits);
     if (r->d_samples) (void)hipFree(r->d_samples);
     if (r->d_sum) (void)hipFree(r->d_sum);
+    if (r->d_rgba8) (void)hipFree(r->d_rgba8);
+    r->d_rgba8 = nullptr;
     if (r->d_counts) (void)hipFree(r->d_counts);
     r->d_counts = nullptr;
     r->d_hits = nullptr;
@@ -218,6 +221,7 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
     PT_HIP(hipMalloc(&r->d_hits, static_cast<size_t>(r->region_pitch) * r->region_size * sizeof(float4)));
     PT_HIP(hipMalloc(&r->d_samples, r->capacity * sizeof(float4)));
     PT_HIP(hipMalloc(&r->d_sum, n_pixels * sizeof(float4)));
+    if (r->cfg.emulate_rgba8) PT_HIP(hipMalloc(&r->d_rgba8, n_pixels * 4));
     PT_HIP(hipMemsetAsync(r->d_sum, 0, n_pixels * sizeof(float4), r->stream));
     r->cam.width = width;
     r->cam.height = height;
@@ -271,6 +275,7 @@ int reset_accumulation(pt_renderer *r)
 {
     PT_HIP(hipMemsetAsync(r->d_sum, 0, static_cast<size_t>(r->width) * r->height * sizeof(float4), r->stream));
     PT_HIP(hipMemsetAsync(r->d_counters, 0, 14 * sizeof(unsigned long long), r->stream));
+    if (r->d_rgba8) PT_HIP(hipMemsetAsync(r->d_rgba8, 0, static_cast<size_t>(r->width) * r->height * 4, r->stream));
     r->local_iterations = 0;
     r->paths = 0;
     for (int k = 0; k < 4; ++k) {
@@ -330,7 +335,9 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     }
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = r->q[b & 1], &out = r->q[(b + 1) & 1];
-        const bool last = (b + 1 == depth);
+        // The last surface hit needs no new direction -- except that the reference still evaluates the BSDF
+        // there, and a NaN it produces becomes the path's sample: the 8-bit emulation runs that last shade too.
+        const bool last = (b + 1 == depth) && !r->cfg.emulate_rgba8;
         const int hit_row = static_cast<int>(depth + 1 + b);
         {
             Timed t(r, 1);
@@ -341,13 +348,14 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
         if (!last) {
             Timed t(r, 2);
             pt::launch_shade(r->stream, g, r->view, regions_for(r, n_paths, static_cast<uint32_t>(hit_row), static_cast<int>(b) + 1), in,
-                             r->d_hits, out);
+                             r->d_hits, out, r->d_samples);
         }
     }
     {
         Timed t(r, 3);
         pt::launch_accumulate(r->stream, shape_for(r, n_pixels), r->d_samples, r->d_sum, static_cast<uint32_t>(n_pixels), kb,
-                              r->d_counts, depth, regions_for(r, n_paths, 0, -1).n_regions, r->region_pitch, r->d_counters, r->d_counters + 12);
+                              r->d_counts, depth, regions_for(r, n_paths, 0, -1).n_regions, r->region_pitch, r->d_counters, r->d_counters + 12,
+                              r->d_counters + 1, r->d_rgba8, it_first, r->world);
     }
     PT_HIP(hipGetLastError());
     if (r->cfg.profile & 1u) {
@@ -682,6 +690,7 @@ void pt_config_default(pt_config *cfg)
     cfg->use_bvh = 1;
     cfg->iterations_per_batch = 0;
     cfg->profile = 0;
+    cfg->emulate_rgba8 = 0;
 }
 
 int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer **out)
@@ -798,6 +807,8 @@ int pt_reset(pt_renderer *r)
 int pt_set_partition(pt_renderer *r, uint32_t rank, uint32_t world)
 {
     PT_REQUIRE(r && world >= 1 && rank < world, "pt_set_partition: need rank < world");
+    if (r->cfg.emulate_rgba8 && world != 1)
+        return fail(PT_ERR_STATE, "pt_set_partition: the 8-bit running average cannot be partitioned");
     PT_HIP(hipSetDevice(r->device));
     r->rank = rank;
     r->world = world;
@@ -833,6 +844,7 @@ struct StateHeader {
 int pt_save_state(pt_renderer *r, const char *path)
 {
     PT_REQUIRE(r && path, "pt_save_state: null argument");
+    if (r->d_rgba8) return fail(PT_ERR_STATE, "pt_save_state: not available with emulate_rgba8");
     PT_HIP(hipSetDevice(r->device));
     const size_t n = static_cast<size_t>(r->width) * r->height * 4;
     std::vector<float> sum(n);
@@ -871,6 +883,7 @@ int pt_save_state(pt_renderer *r, const char *path)
 int pt_load_state(pt_renderer *r, const char *path)
 {
     PT_REQUIRE(r && path, "pt_load_state: null argument");
+    if (r->d_rgba8) return fail(PT_ERR_STATE, "pt_load_state: not available with emulate_rgba8");
     PT_HIP(hipSetDevice(r->device));
     FILE *f = std::fopen(path, "rb");
     if (!f) return fail(PT_ERR_IO, std::string("pt_load_state: cannot open ") + path);
@@ -915,6 +928,16 @@ int pt_read_sum(pt_renderer *r, float *rgba)
     PT_HIP(hipSetDevice(r->device));
     PT_HIP(hipMemcpyAsync(rgba, r->d_sum, static_cast<size_t>(r->width) * r->height * sizeof(float4), hipMemcpyDeviceToHost,
                           r->stream));
+    PT_HIP(hipStreamSynchronize(r->stream));
+    return PT_OK;
+}
+
+int pt_read_rgba8(pt_renderer *r, uint8_t *rgba)
+{
+    PT_REQUIRE(r && rgba, "pt_read_rgba8: null argument");
+    if (!r->d_rgba8) return fail(PT_ERR_STATE, "pt_read_rgba8: the renderer was created without emulate_rgba8");
+    PT_HIP(hipSetDevice(r->device));
+    PT_HIP(hipMemcpyAsync(rgba, r->d_rgba8, static_cast<size_t>(r->width) * r->height * 4, hipMemcpyDeviceToHost, r->stream));
     PT_HIP(hipStreamSynchronize(r->stream));
     return PT_OK;
 }
