@@ -168,8 +168,15 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # Rehearsal on a one-GPU box: every rank on GPU 0 and gloo instead of RCCL (RCCL refuses two ranks on one
+        # device).  Exercises the multi-rank control flow only; its numbers mean nothing.
+        rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        if distributed:
+        if distributed and rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        elif distributed:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     import pathtracer_amd as pt
 

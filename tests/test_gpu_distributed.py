@@ -16,3 +16,30 @@ def test_sum_buffer_alias_and_rccl_collective():
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "rccl_single_rank.py")
     out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=240)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py launched the way the scaling run launches it (torch.distributed.run, one process per
+    rank), with both ranks on the one GPU and gloo in place of RCCL: the sample partition, the reduce
+    into rank 0 and the one JSON line."""
+    import json
+    import socket
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PT_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--width", "256", "--height", "256", "--spp-per-step", "4", "--no-cpu-baseline", "--no-extra"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "Mpaths/s"
+    assert d["config"]["paths_per_step"] == 256 * 256 * 4 * 2
+    assert d["gates"]["samples_per_pixel_root"] == 3 * 4 * 2  # both ranks' samples arrived at the root
+    assert d["gates"]["primary_hit_ids_bit_exact_vs_reference"] is True
+    assert d["value"] > 0 and "roofline" in d and "cpu_baseline" not in d
