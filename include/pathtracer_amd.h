@@ -89,7 +89,7 @@ typedef struct {
     /* Scheduling diagnostics of the extend kernel (profile bit 1), per wave:
      * inner-node loop iterations, lanes active in them, triangle-loop
      * iterations, lane-triangle tests, rounds, lanes holding a ray per round,
-     * refills, rays handed out. */
+     * sum over waves of their busy time and the longest single wave (100 MHz ticks). */
     uint64_t extend_diag[8];
     /* Lane occupancy of the shade kernel after compaction: surface hits shaded and
      * the 64-lane batches they were processed in (fill = hits / (64 * batches)). */

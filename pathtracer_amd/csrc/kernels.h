@@ -57,7 +57,7 @@ struct TraversalCounters {
     // [0] phase-A loop iterations (per wave) [1] lanes active in them
     // [2] phase-B triangle-loop iterations   [3] lane-triangle tests in them
     // [4] rounds (A + B)                     [5] lanes holding a ray per round
-    // [6] refills                            [7] rays handed out by refills
+    // [6] sum over waves of their busy time  [7] longest busy time of one wave (100 MHz ticks)
     unsigned long long *diag;
 };
 
