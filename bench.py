@@ -36,7 +36,7 @@ EXTEND_READ_PER_RAY = 32               # origin/direction lanes of every ray
 EXTEND_WRITE_PER_HIT = 16              # hit-list record of a surface hit that will be shaded
 SHADE_READ_PER_HIT = 16 + 48           # hit record + path state
 SHADE_WRITE_PER_SURVIVOR = 48          # compacted state of a surviving path
-RAYGEN_BYTES_PER_PATH = 48 + 16        # path state + zeroed sample slot
+RAYGEN_BYTES_PER_PATH = 32 + 4         # origin / direction / seed lanes + light distance (p2 is derived, samples are tagged)
 SAMPLE_BYTES = 16                      # one radiance sample per path (read by accumulate)
 
 

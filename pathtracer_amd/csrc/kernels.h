@@ -23,6 +23,7 @@ struct SceneView {
 
 // One path queue: three 16-byte lanes per path.
 //   p0 = (origin.xyz, dir.x)  p1 = (dir.y, dir.z, seed.x, seed.y)  p2 = (throughput.rgb, sample slot)
+// (p2 is not stored for primary rays: ExtendOutput::primary_of)
 // lt: with exactly one light in the scene, the distance at which the ray meets it (frag:363-382), computed by
 // the kernel that creates the ray; < 0 when it does not.  The traversal then starts with that distance as its
 // limit instead of testing the light when the ray finishes.
@@ -70,8 +71,7 @@ struct LaunchShape {
 
 // counts_out: n_regions live counts of bounce 0.
 void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, DeviceCamera cam, uint32_t it_first,
-                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_size,
-                   float4 *samples /* zeroed per path when not null */);
+                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_size);
 
 // Where extend puts its results.
 //  render = false: hit_list is written as a float2 array, results[slot] = (t, hit code), for every ray
@@ -88,6 +88,10 @@ struct ExtendOutput {
     bool render;
     bool last_segment;
     bool exact_parallel;
+    uint32_t sample_tag = 0;  // written into the w lane of every sample of this batch (see launch_accumulate)
+    // First segment of a batch made by launch_raygen: lane p2 (throughput 1, the path's own sample slot) is not
+    // stored for it but derived from the queue slot with the camera's slot -> pixel mapping.
+    const DeviceCamera *primary_of = nullptr;
 };
 
 // stack_entries: entries of the per-lane traversal stack in LDS (>= BVH depth).
@@ -102,14 +106,17 @@ uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t 
                                bool scene_in_lds);
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
-                  const float4 *hit_list, PathQueue out, float4 *samples /* receives the NaN sample of a path whose throughput went non-finite */);
+                  const float4 *hit_list, PathQueue out, float4 *samples /* receives the NaN sample of a path whose throughput went non-finite */,
+                  uint32_t sample_tag, const DeviceCamera *primary_of /* as in ExtendOutput, may be null */);
 
+// The sample buffer is never cleared: a path that ends on a light writes (radiance, tag) with the tag of its
+// batch, and a slot whose w lane does not carry this batch's tag counts as a zero sample (a path that escaped).
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
                        uint32_t pitch, unsigned long long *segments_total,
                        unsigned long long *shade_totals /* [0] surface hits shaded, [1] 64-lane batches formed */,
                        unsigned long long *nan_counter, uint8_t *rgba8 /* may be null */, uint32_t it_first,
-                       uint32_t it_stride);
+                       uint32_t it_stride, uint32_t sample_tag);
 
 // hits -> int32 hit codes / t / directions in pixel order for one iteration.
 // cam: the camera whose raygen made the rays (its slot -> pixel mapping orders the output by pixel); null: rays

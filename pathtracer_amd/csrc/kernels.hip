@@ -123,10 +123,18 @@ __device__ __forceinline__ uint32_t pixel_of_slot(const DeviceCamera &cam, uint3
     return ((ty << 3) + (in_unit >> 3)) * cam.width + (tx << 3) + (in_unit & 7u);
 }
 
+// Lane p2 of a primary ray: throughput 1 and the slot of the path's sample, iteration_in_batch * W*H + pixel.
+__device__ __forceinline__ float4 primary_p2(const DeviceCamera &cam, uint32_t slot)
+{
+    const uint32_t n_pixels = cam.width * cam.height;
+    const uint32_t k = slot / n_pixels;
+    return make_float4(1.f, 1.f, 1.f, __uint_as_float(k * n_pixels + pixel_of_slot(cam, slot - k * n_pixels)));
+}
+
 // frag:866 + frag:306-320.  Path slot i = k * (W*H) + j, j-th slot of iteration k -> pixel_of_slot.
 __global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
                                                     uint32_t n_iterations, PathQueue out, uint32_t *counts_out,
-                                                    uint32_t region_slots, float4 *__restrict__ samples)
+                                                    uint32_t region_slots)
 {
     const uint32_t n_pixels = cam.width * cam.height;
     const uint32_t total = n_pixels * n_iterations;
@@ -155,10 +163,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, DeviceCamera ca
         const f3 d = normalizem(p - eye);
         out.p0[i] = make_float4(eye.x, eye.y, eye.z, d.x);
         out.p1[i] = make_float4(d.y, d.z, __uint_as_float(sx), __uint_as_float(sy));
-        out.p2[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(k * n_pixels + pixel));
         if (sc.n_lights == 1u) out.lt[i] = light_distance(sc.lights[0], eye, d);
-        // Only a path that reaches a light writes its sample; everything else adds zero.
-        if (samples) samples[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i % region_slots == 0u) counts_out[i / region_slots] = min(region_slots, total - i);
     }
 }
@@ -247,7 +252,8 @@ __device__ __forceinline__ void append_hit(float4 *__restrict__ hit_list, uint32
 template <bool RENDER>
 __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg, PathQueue q,
                                                          float4 *__restrict__ hit_list, float4 *__restrict__ samples,
-                                                         unsigned long long *__restrict__ nan_counter, uint32_t last_segment)
+                                                         unsigned long long *__restrict__ nan_counter, uint32_t last_segment,
+                                                         uint32_t sample_tag, DeviceCamera cam, uint32_t primary)
 {
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     const uint32_t lane = threadIdx.x & 63u;
@@ -275,11 +281,11 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
             if (!RENDER) {
                 results[i] = make_float2(t, __int_as_float(code));
             } else if (code <= -2) {
-                const float4 c = q.p2[i];
+                const float4 c = primary ? primary_p2(cam, i) : q.p2[i];
                 const float *rad = sc.lights[-(code + 2)].radiance;
                 const f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
                 // a non-finite sample is left to the accumulate kernel (which drops and counts it)
-                samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, 1.f);
+                samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, __uint_as_float(sample_tag));
             } else {
                 append = code >= 0 && last_segment == 0u;
             }
@@ -338,7 +344,8 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                                                         float4 *__restrict__ hit_list, float4 *__restrict__ samples,
                                                         unsigned long long *__restrict__ nan_counter, uint32_t last_segment,
                                                         TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
-                                                        uint32_t stack_entries, uint32_t n_lds_nodes)
+                                                        uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t sample_tag,
+                                                        DeviceCamera cam, uint32_t primary)
 {
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     extern __shared__ float4 lds[];
@@ -560,11 +567,11 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                     results[slot] = make_float2(hit_t, __int_as_float(hit_code));
                 } else if (hit_code <= -2) {
                     // passCol = attenuation * intensity (frag:878-882, :901)
-                    const float4 c = q.p2[slot];
+                    const float4 c = primary ? primary_p2(cam, slot) : q.p2[slot];
                     const float *rad = sc.lights[-(hit_code + 2)].radiance;
                     const f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
                     // a non-finite sample is left to the accumulate kernel (which drops and counts it)
-                    samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, 1.f);
+                    samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, __uint_as_float(sample_tag));
                 } else {
                     append = hit_code >= 0 && last_segment == 0u;
                 }
@@ -907,7 +914,8 @@ __device__ __forceinline__ Material load_material(const SceneView &sc, uint32_t 
 // simply is not written: its sample slot already holds zero.
 __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, Regions rg, PathQueue in,
                                                    const float4 *__restrict__ hit_list, PathQueue out,
-                                                   float4 *__restrict__ samples)
+                                                   float4 *__restrict__ samples, uint32_t sample_tag,
+                                                   DeviceCamera cam, uint32_t primary)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
@@ -958,7 +966,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
         if (take0 || take1) {
             const float4 rec = hit_list[region_base + (take1 ? last_slot - j : j)];
             const uint32_t i = region_base + __float_as_uint(rec.z);
-            const float4 a = in.p0[i], b = in.p1[i], c = in.p2[i];
+            const float4 a = in.p0[i], b = in.p1[i], c = primary ? primary_p2(cam, i) : in.p2[i];
             const int code = __float_as_int(rec.y);
             const f3 thr = mk(c.x, c.y, c.z);
             {
@@ -1002,7 +1010,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
                         if (!isfinite(att.x) && !isfinite(att.y) && !isfinite(att.z)) {
                             dead = true;
                             const float nan = __builtin_nanf("");
-                            samples[__float_as_uint(c.w)] = make_float4(nan, nan, nan, 1.f);
+                            samples[__float_as_uint(c.w)] = make_float4(nan, nan, nan, __uint_as_float(sample_tag));
                         }
                     }
                 }
@@ -1051,7 +1059,8 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
                                                         unsigned long long *__restrict__ segments_total,
                                                         unsigned long long *__restrict__ shade_totals,
                                                         unsigned long long *__restrict__ nan_counter,
-                                                        uint8_t *__restrict__ rgba8, uint32_t it_first, uint32_t it_stride)
+                                                        uint8_t *__restrict__ rgba8, uint32_t it_first, uint32_t it_stride,
+                                                        uint32_t sample_tag)
 {
     {
         // surface hits shaded in this batch and the 64-lane batches the shade kernel formed of them
@@ -1085,7 +1094,8 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
         float4 acc = sum[p];
         uchar4 tex = rgba8 ? reinterpret_cast<uchar4 *>(rgba8)[p] : make_uchar4(0, 0, 0, 0);
         for (uint32_t k = 0; k < n_iterations; ++k) {
-            const float4 s = samples[static_cast<size_t>(k) * n_pixels + p];
+            float4 s = samples[static_cast<size_t>(k) * n_pixels + p];
+            if (__float_as_uint(s.w) != sample_tag) s = make_float4(0.f, 0.f, 0.f, 0.f);  // not written in this batch: the path escaped
             if (isfinite(s.x) && isfinite(s.y) && isfinite(s.z)) {
                 acc.x += s.x;
                 acc.y += s.y;
@@ -1227,11 +1237,10 @@ uint32_t resident_grid(K kernel, size_t lds_bytes, LaunchShape g, int block = kB
 }  // namespace
 
 void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, DeviceCamera cam, uint32_t it_first,
-                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_size,
-                   float4 *samples)
+                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_size)
 {
     hipLaunchKernelGGL(k_raygen, dim3(g.blocks), dim3(kBlock), 0, s, scene, cam, it_first, it_stride, n_iterations, out,
-                       counts_out, region_size, samples);
+                       counts_out, region_size);
 }
 
 namespace {
@@ -1304,15 +1313,17 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         return static_cast<uint32_t>(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     const bool render = out.render;
+    const uint32_t primary = out.primary_of ? 1u : 0u;
+    const DeviceCamera primary_cam = out.primary_of ? *out.primary_of : DeviceCamera{};
     const bool exact_parallel = out.exact_parallel && !render;
     const uint32_t last = out.last_segment ? 1u : 0u;
     if (!use_bvh) {
         if (render)
             hipLaunchKernelGGL(k_extend_scan<true>, dim3(resident_grid(k_extend_scan<true>, 0, g)), dim3(kBlock), 0, s, scene,
-                               regions, q, out.hit_list, out.samples, out.nan_counter, last);
+                               regions, q, out.hit_list, out.samples, out.nan_counter, last, out.sample_tag, primary_cam, primary);
         else
             hipLaunchKernelGGL(k_extend_scan<false>, dim3(resident_grid(k_extend_scan<false>, 0, g)), dim3(kBlock), 0, s, scene,
-                               regions, q, out.hit_list, out.samples, out.nan_counter, last);
+                               regions, q, out.hit_list, out.samples, out.nan_counter, last, out.sample_tag, primary_cam, primary);
         return;
     }
     const bool counting = tc.nodes_visited != nullptr;
@@ -1330,7 +1341,8 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         hipLaunchKernelGGL((k_extend_bvh<C, E, L, R, T>),                                                         \
                            dim3(resident_grid(k_extend_bvh<C, E, L, R, T>, lds_bytes, g, kExtBlock)),               \
                            dim3(kExtBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples,            \
-                           out.nan_counter, last, tc, n_nodes, refill_at, stack_entries, n_lds_nodes);            \
+                           out.nan_counter, last, tc, n_nodes, refill_at, stack_entries, n_lds_nodes, out.sample_tag,   \
+                           primary_cam, primary);            \
     } while (0)
 #define PT_LAUNCH_EXTEND1(L)                                                                                       \
     do {                                                                                                          \
@@ -1360,20 +1372,22 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
 }
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
-                  const float4 *hit_list, PathQueue out, float4 *samples)
+                  const float4 *hit_list, PathQueue out, float4 *samples, uint32_t sample_tag,
+                  const DeviceCamera *primary_of)
 {
     hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g)), dim3(kBlock), 0, s, scene, regions, in, hit_list, out,
-                       samples);
+                       samples, sample_tag, primary_of ? *primary_of : DeviceCamera{}, primary_of ? 1u : 0u);
 }
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
                        uint32_t pitch, unsigned long long *segments_total, unsigned long long *shade_totals,
-                       unsigned long long *nan_counter, uint8_t *rgba8, uint32_t it_first, uint32_t it_stride)
+                       unsigned long long *nan_counter, uint8_t *rgba8, uint32_t it_first, uint32_t it_stride,
+                       uint32_t sample_tag)
 {
     hipLaunchKernelGGL(k_accumulate, dim3(g.blocks), dim3(kBlock), 0, s, samples, sum, n_pixels, n_iterations, counts,
                        n_rows, n_regions, pitch, segments_total, shade_totals, nan_counter,
-                       rgba8, it_first, it_stride);
+                       rgba8, it_first, it_stride, sample_tag);
 }
 
 void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *hits, int32_t *ids,

@@ -115,6 +115,7 @@ struct pt_renderer {
     pt::PathQueue q[2] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
     float4 *d_hits = nullptr;                 // hit list of the render loop; (t, code) results of the readbacks
     float4 *d_samples = nullptr;
+    uint32_t sample_tag = 0;                  // batch counter; tags the samples written in the current batch
     float4 *d_sum = nullptr;
     uint32_t *d_counts = nullptr;             // (max_depth + 1) rows of region_pitch live counts, one row per bounce
     uint32_t region_pitch = 0;                // regions the queues hold at full capacity
@@ -220,6 +221,8 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
     // whole regions: the hit list of a region is filled from both of its ends
     PT_HIP(hipMalloc(&r->d_hits, static_cast<size_t>(r->region_pitch) * r->region_size * sizeof(float4)));
     PT_HIP(hipMalloc(&r->d_samples, r->capacity * sizeof(float4)));
+    PT_HIP(hipMemsetAsync(r->d_samples, 0, r->capacity * sizeof(float4), r->stream));  // tag 0 = never written
+    r->sample_tag = 0;
     PT_HIP(hipMalloc(&r->d_sum, n_pixels * sizeof(float4)));
     if (r->cfg.emulate_rgba8) PT_HIP(hipMalloc(&r->d_rgba8, n_pixels * 4));
     PT_HIP(hipMemsetAsync(r->d_sum, 0, n_pixels * sizeof(float4), r->stream));
@@ -329,9 +332,10 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     pt::TraversalCounters tc{nullptr, nullptr, nullptr};
     if (r->cfg.profile & 2u) tc = pt::TraversalCounters{r->d_counters + 2, r->d_counters + 3, r->d_counters + 4};
     const pt::LaunchShape g = shape_for(r, n_paths);
+    if (++r->sample_tag == 0u) r->sample_tag = 1u;  // 0 is the tag of the cleared buffer
     {
         Timed t(r, 0);
-        pt::launch_raygen(r->stream, g, r->view, r->cam, it_first, r->world, kb, r->q[0], r->d_counts, r->region_size, r->d_samples);
+        pt::launch_raygen(r->stream, g, r->view, r->cam, it_first, r->world, kb, r->q[0], r->d_counts, r->region_size);
     }
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = r->q[b & 1], &out = r->q[(b + 1) & 1];
@@ -341,21 +345,22 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
         const int hit_row = static_cast<int>(depth + 1 + b);
         {
             Timed t(r, 1);
-            pt::ExtendOutput eo{true, r->d_hits, r->d_samples, r->d_counters + 1, true, last, false};
+            pt::ExtendOutput eo{true, r->d_hits, r->d_samples, r->d_counters + 1, true, last, false, r->sample_tag,
+                                b == 0 ? &r->cam : nullptr};
             pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, hit_row), in,
                               eo, tc, r->n_nodes, r->scene_in_lds);
         }
         if (!last) {
             Timed t(r, 2);
             pt::launch_shade(r->stream, g, r->view, regions_for(r, n_paths, static_cast<uint32_t>(hit_row), static_cast<int>(b) + 1), in,
-                             r->d_hits, out, r->d_samples);
+                             r->d_hits, out, r->d_samples, r->sample_tag, b == 0 ? &r->cam : nullptr);
         }
     }
     {
         Timed t(r, 3);
         pt::launch_accumulate(r->stream, shape_for(r, n_pixels), r->d_samples, r->d_sum, static_cast<uint32_t>(n_pixels), kb,
                               r->d_counts, depth, regions_for(r, n_paths, 0, -1).n_regions, r->region_pitch, r->d_counters, r->d_counters + 12,
-                              r->d_counters + 1, r->d_rgba8, it_first, r->world);
+                              r->d_counters + 1, r->d_rgba8, it_first, r->world, r->sample_tag);
     }
     PT_HIP(hipGetLastError());
     if (r->cfg.profile & 1u) {
@@ -998,7 +1003,7 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
     if (t) PT_TRY(hipMalloc(&d_t, n * sizeof(float)));
     if (dirs) PT_TRY(hipMalloc(&d_dirs, 3 * n * sizeof(float)));
     const pt::LaunchShape g = shape_for(r, n);
-    pt::launch_raygen(r->stream, g, r->view, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_size, nullptr);
+    pt::launch_raygen(r->stream, g, r->view, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_size);
     pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0],
                       pt::ExtendOutput{true, r->d_hits, nullptr, nullptr, false, false, r->exact_readbacks},
                       pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
