@@ -32,10 +32,10 @@ VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (spec, FMA = 2 flops)
 
 # Algorithmic HBM bytes per work item with the queue records this build uses
 # (three 16-byte lanes of path state, a 16-byte hit record, a 16-byte sample):
-EXTEND_READ_PER_RAY = 32               # origin/direction lanes of every ray
+EXTEND_READ_PER_RAY = 32 + 4           # origin/direction lanes + light distance of every ray
 EXTEND_WRITE_PER_HIT = 16              # hit-list record of a surface hit that will be shaded
 SHADE_READ_PER_HIT = 16 + 48           # hit record + path state
-SHADE_WRITE_PER_SURVIVOR = 48          # compacted state of a surviving path
+SHADE_WRITE_PER_SURVIVOR = 48 + 4      # compacted state of a surviving path + its light distance
 RAYGEN_BYTES_PER_PATH = 32 + 4         # origin / direction / seed lanes + light distance (p2 is derived, samples are tagged)
 SAMPLE_BYTES = 16                      # one radiance sample per path (read by accumulate)
 
