@@ -84,7 +84,6 @@ struct ExtendOutput {
     bool light_distance_in_queue;  // q.lt is valid (rays made by raygen / shade in a one-light scene)
     float4 *hit_list;
     float4 *samples;
-    unsigned long long *nan_counter;
     bool render;
     bool last_segment;
     bool exact_parallel;

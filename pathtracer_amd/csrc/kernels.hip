@@ -252,7 +252,7 @@ __device__ __forceinline__ void append_hit(float4 *__restrict__ hit_list, uint32
 template <bool RENDER>
 __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg, PathQueue q,
                                                          float4 *__restrict__ hit_list, float4 *__restrict__ samples,
-                                                         unsigned long long *__restrict__ nan_counter, uint32_t last_segment,
+                                                         uint32_t last_segment,
                                                          uint32_t sample_tag, DeviceCamera cam, uint32_t primary)
 {
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 template <bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER, bool USE_LT>
 __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
                                                         float4 *__restrict__ hit_list, float4 *__restrict__ samples,
-                                                        unsigned long long *__restrict__ nan_counter, uint32_t last_segment,
+                                                        uint32_t last_segment,
                                                         TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
                                                         uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t sample_tag,
                                                         DeviceCamera cam, uint32_t primary)
@@ -1320,10 +1320,10 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     if (!use_bvh) {
         if (render)
             hipLaunchKernelGGL(k_extend_scan<true>, dim3(resident_grid(k_extend_scan<true>, 0, g)), dim3(kBlock), 0, s, scene,
-                               regions, q, out.hit_list, out.samples, out.nan_counter, last, out.sample_tag, primary_cam, primary);
+                               regions, q, out.hit_list, out.samples, last, out.sample_tag, primary_cam, primary);
         else
             hipLaunchKernelGGL(k_extend_scan<false>, dim3(resident_grid(k_extend_scan<false>, 0, g)), dim3(kBlock), 0, s, scene,
-                               regions, q, out.hit_list, out.samples, out.nan_counter, last, out.sample_tag, primary_cam, primary);
+                               regions, q, out.hit_list, out.samples, last, out.sample_tag, primary_cam, primary);
         return;
     }
     const bool counting = tc.nodes_visited != nullptr;
@@ -1341,7 +1341,7 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         hipLaunchKernelGGL((k_extend_bvh<C, E, L, R, T>),                                                         \
                            dim3(resident_grid(k_extend_bvh<C, E, L, R, T>, lds_bytes, g, kExtBlock)),               \
                            dim3(kExtBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples,            \
-                           out.nan_counter, last, tc, n_nodes, refill_at, stack_entries, n_lds_nodes, out.sample_tag,   \
+                           last, tc, n_nodes, refill_at, stack_entries, n_lds_nodes, out.sample_tag,   \
                            primary_cam, primary);            \
     } while (0)
 #define PT_LAUNCH_EXTEND1(L)                                                                                       \

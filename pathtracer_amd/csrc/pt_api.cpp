@@ -345,7 +345,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
         const int hit_row = static_cast<int>(depth + 1 + b);
         {
             Timed t(r, 1);
-            pt::ExtendOutput eo{true, r->d_hits, r->d_samples, r->d_counters + 1, true, last, false, r->sample_tag,
+            pt::ExtendOutput eo{true, r->d_hits, r->d_samples, true, last, false, r->sample_tag,
                                 b == 0 ? &r->cam : nullptr};
             pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, hit_row), in,
                               eo, tc, r->n_nodes, r->scene_in_lds);
@@ -1005,7 +1005,7 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
     const pt::LaunchShape g = shape_for(r, n);
     pt::launch_raygen(r->stream, g, r->view, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_size);
     pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0],
-                      pt::ExtendOutput{true, r->d_hits, nullptr, nullptr, false, false, r->exact_readbacks},
+                      pt::ExtendOutput{true, r->d_hits, nullptr, false, false, r->exact_readbacks},
                       pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
     pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(n), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids, d_t,
                               d_dirs, &r->cam);
@@ -1046,7 +1046,7 @@ int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float 
         const pt::LaunchShape g = shape_for(r, c);
         pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], r->d_counts, r->region_size);
         pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, c, 0, -1), r->q[0],
-                          pt::ExtendOutput{false, r->d_hits, nullptr, nullptr, false, false, r->exact_readbacks},
+                          pt::ExtendOutput{false, r->d_hits, nullptr, false, false, r->exact_readbacks},
                           pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
         pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(c), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids,
                                   d_t, nullptr, nullptr);
