@@ -71,6 +71,13 @@ typedef struct {
                                       iteration (frag:900-904, renderer.cpp:21,25), NaN
                                       samples and all.  Single renderer only (the running
                                       average is not a sum and cannot be partitioned).   */
+    uint32_t bvh_builder;          /* 0: the tree is built on the host (threads) and uploaded;
+                                      1: it is built on the GPU from the uploaded triangles.
+                                      Both make the same tree; the device build takes
+                                      milliseconds where the host takes seconds on ten
+                                      million triangles.  pt_create fails with the device
+                                      builder on input that needs the host builder's
+                                      object-median fall-back (see pt_last_error).        */
 } pt_config;
 
 typedef struct {
@@ -94,6 +101,8 @@ typedef struct {
     /* Lane occupancy of the shade kernel after compaction: surface hits shaded and
      * the 64-lane batches they were processed in (fill = hits / (64 * batches)). */
     uint64_t hits_shaded, shade_batches;
+    uint32_t bvh_builder;     /* the builder that made the tree: 0 host, 1 device */
+    uint32_t reserved;
 } pt_stats;
 
 const char *pt_last_error(void);
@@ -221,6 +230,14 @@ typedef struct {
     double sah_cost, build_ms;
 } pt_bvh_info;
 int pt_bvh_inspect(const pt_scene_desc *scene, pt_bvh_info *info);
+/* The renderer's tree as it lies in device memory, for comparing the two builders:
+ * nodes_host receives n_nodes records of 16 words (two child boxes as 12 floats, then
+ * the two child codes as int32 and two zero words), triangles_host n_triangles
+ * records of 16 words in leaf order (v0 xyz, d0, v1 xyz, n.x, v2 xyz, n.y, n.z, the
+ * original triangle index with bit 30 set on surfaces that are not purely diffuse,
+ * two zero words).  Either pointer may be null.  Sizes: pt_get_stats.  No reference
+ * counterpart. */
+int pt_read_bvh(pt_renderer *r, float *nodes_host, float *triangles_host);
 
 #ifdef __cplusplus
 }

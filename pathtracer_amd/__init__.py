@@ -67,6 +67,7 @@ class Config(C.Structure):
         ("iterations_per_batch", C.c_uint32),
         ("profile", C.c_uint32),
         ("emulate_rgba8", C.c_uint32),
+        ("bvh_builder", C.c_uint32),
     ]
 
 
@@ -109,6 +110,8 @@ class Stats(C.Structure):
         ("extend_diag", C.c_uint64 * 8),
         ("hits_shaded", C.c_uint64),
         ("shade_batches", C.c_uint64),
+        ("bvh_builder", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:
@@ -156,6 +159,7 @@ _SIGNATURES = {
     "pt_set_partition": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "pt_synchronize": (C.c_int, [_vp]),
     "pt_read_rgba8": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
+    "pt_read_bvh": (C.c_int, [_vp, _f32p, _f32p]),
     "pt_save_state": (C.c_int, [_vp, C.c_char_p]),
     "pt_load_state": (C.c_int, [_vp, C.c_char_p]),
     "pt_read_sum": (C.c_int, [_vp, _f32p]),
@@ -366,7 +370,8 @@ class Renderer:
 
     def __init__(self, scene: Scene, camera: Optional[Camera] = None, *, max_depth: int = 10,
                  fov_y_degrees: float = 19.5, device: int = -1, use_bvh: bool = True,
-                 iterations_per_batch: int = 0, profile: int = 0, emulate_rgba8: bool = False):
+                 iterations_per_batch: int = 0, profile: int = 0, emulate_rgba8: bool = False,
+                 bvh_builder: str = "host"):
         self.scene = scene
         self.camera = camera if camera is not None else Camera()
         w, h = self.camera.resolution
@@ -380,6 +385,9 @@ class Renderer:
         cfg.iterations_per_batch = iterations_per_batch
         cfg.profile = int(profile)  # bit 0: per-launch HIP-event timing; bit 1: traversal counters
         cfg.emulate_rgba8 = 1 if emulate_rgba8 else 0
+        if bvh_builder not in ("host", "device"):
+            raise ValueError("bvh_builder is 'host' or 'device'")
+        cfg.bvh_builder = 1 if bvh_builder == "device" else 0
         self.config = cfg
         self._h = _vp()
         d = scene.desc()
@@ -438,6 +446,15 @@ class Renderer:
         out = np.zeros((self.height, self.width, 4), np.float32)
         _check(_lib.pt_read_radiance(self._h, _ptr(out, _f32p)))
         return out
+
+    def read_bvh(self):
+        """(nodes, triangles) as they lie in device memory: nodes n x 16 float32 words (two child
+        boxes, then the child codes as int32 bits), triangles T x 16 words in leaf order."""
+        st = self.stats()
+        nodes = np.zeros((st["n_nodes"], 16), np.float32)
+        tris = np.zeros((st["n_triangles"], 16), np.float32)
+        _check(_lib.pt_read_bvh(self._h, _ptr(nodes, _f32p), _ptr(tris, _f32p)))
+        return nodes, tris
 
     def read_rgba8(self) -> np.ndarray:
         """The emulated 8-bit accumulation texture (emulate_rgba8=True), H x W x 4, row 0 = bottom row."""

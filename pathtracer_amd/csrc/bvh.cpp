@@ -98,11 +98,15 @@ struct Builder {
         const uint32_t n = end - begin;
         int32_t self = static_cast<int32_t>(tmp.size());
         tmp.push_back(node);
-        if (n <= 1u || (n <= kLeafMax && (median_only || level >= 48))) {
+        // A leaf lists its triangles by index, whatever order the partitioning left them in, so that
+        // the tree is a function of the triangle set alone.
+        auto make_leaf = [&]() {
+            std::sort(prims.begin() + begin, prims.begin() + end, [](const Prim &a, const Prim &b) { return a.id < b.id; });
             tmp[self].first = begin;
             tmp[self].count = n;
             return self;
-        }
+        };
+        if (n <= 1u || (n <= kLeafMax && (median_only || level >= 48))) return make_leaf();
         if (jobs && n <= job_size && n > 4u * kLeafMax) {
             jobs->push_back(Job{begin, end, level, self});
             return self;
@@ -159,11 +163,8 @@ struct Builder {
             // A small group stays a leaf unless splitting it pays for the extra box test
             // (surface-area heuristic: kTraversalCost box tests against saved triangle tests).
             if (n <= kLeafMax && (best_axis < 0 || double(n) * node.box.half_area() <=
-                                                       kTraversalCost * node.box.half_area() + best)) {
-                tmp[self].first = begin;
-                tmp[self].count = n;
-                return self;
-            }
+                                                       kTraversalCost * node.box.half_area() + best))
+                return make_leaf();
             if (best_axis >= 0) {
                 const float lo = cbox.lo[best_axis];
                 const float k = kBins / (cbox.hi[best_axis] - lo);
@@ -181,8 +182,8 @@ struct Builder {
             }
         }
         if (!split_found) {
-            // Object-median split along the widest centroid axis (or by position
-            // in the array when all centroids coincide).
+            // Object-median split along the widest centroid axis (or by triangle
+            // index when all centroids coincide).
             int axis = 0;
             for (int a = 1; a < 3; ++a)
                 if (cbox.hi[a] - cbox.lo[a] > cbox.hi[axis] - cbox.lo[axis]) axis = a;
@@ -193,6 +194,9 @@ struct Builder {
                                      return a.centroid[axis] < b.centroid[axis] ||
                                             (a.centroid[axis] == b.centroid[axis] && a.id < b.id);
                                  });
+            else
+                std::sort(prims.begin() + begin, prims.begin() + end,
+                          [](const Prim &a, const Prim &b) { return a.id < b.id; });
         }
         int32_t l = build(begin, mid, level + 1, tmp, jobs, job_size);
         int32_t r = build(mid, end, level + 1, tmp, jobs, job_size);
@@ -317,6 +321,9 @@ void renumber_top_breadth_first(std::vector<BvhNode> *nodes, size_t top)
 }
 
 }  // namespace
+
+uint32_t bvh_leaf_max() { return kLeafMax; }
+double bvh_traversal_cost() { return kTraversalCost; }
 
 void build_bvh(const float *vertices, const uint32_t *ids, uint32_t n_triangles, uint32_t max_depth, Bvh *out)
 {

@@ -60,4 +60,9 @@ struct Bvh {
 void build_bvh(const float *vertices, const uint32_t *tri_vertex_ids, uint32_t n_triangles,
                uint32_t max_depth, Bvh *out);
 
+// The two constants of the builder's surface-area heuristic: the largest leaf
+// and the cost of one inner-node step in units of one triangle test.
+uint32_t bvh_leaf_max();
+double bvh_traversal_cost();
+
 }  // namespace pt

@@ -8,7 +8,7 @@
 //             [--light r g b  px py pz  rx ry rz  sx sy sz]  repeatable; replaces the default light
 //             [--no-light]
 //             [--resume state.bin] [--save-state state.bin] [--checkpoint-every n]
-//             [--scan] [--out image.ppm] [--pfm radiance.pfm]
+//             [--scan] [--bvh host|device] [--out image.ppm] [--pfm radiance.pfm]
 // --spp is the total: after --resume only the missing samples are rendered.
 #include <algorithm>
 #include <chrono>
@@ -53,7 +53,7 @@ int main(int argc, char **argv)
     uint32_t width = 1280, height = 720, spp = 64, depth = 10;
     float fov = 19.5f;
     pt::Vec3 eye = pt::make3(0.f, 1.5f, 15.f), focus = pt::make3(0.f, -0.25f, 0.f);
-    bool scan = false, no_light = false;
+    bool scan = false, no_light = false, device_bvh = false;
     std::string resume, save_state;
     uint32_t checkpoint_every = 0;
     std::vector<pt::Scene::Light> lights;
@@ -80,6 +80,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--out")) out = next(), ++i;
         else if (!std::strcmp(argv[i], "--pfm")) pfm = next(), ++i;
         else if (!std::strcmp(argv[i], "--scan")) scan = true;
+        else if (!std::strcmp(argv[i], "--bvh")) device_bvh = !std::strcmp(next(), "device"), ++i;
         else if (!std::strcmp(argv[i], "--no-light")) no_light = true;
         else if (!std::strcmp(argv[i], "--resume")) resume = next(), ++i;
         else if (!std::strcmp(argv[i], "--save-state")) save_state = next(), ++i;
@@ -128,7 +129,7 @@ int main(int argc, char **argv)
             else if (m.kind == 'p') camera.pan(m.a, m.b);
             else camera.zoom(m.a);
         }
-        pt::Renderer renderer(&scene, &camera, depth, fov, !scan);
+        pt::Renderer renderer(&scene, &camera, depth, fov, !scan, -1, device_bvh);
         uint32_t done = 0;
         if (!resume.empty()) {
             renderer.loadState(resume);
@@ -148,8 +149,10 @@ int main(int argc, char **argv)
         double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         pt_stats st = renderer.stats();
         const double new_paths = static_cast<double>(done - resumed_at) * width * height;  // segments count this run only
-        std::printf("%zu triangles, %u BVH nodes (depth %u), %ux%u, %u spp, depth %u: %.3f s, %.1f Mpaths/s, %.2f segments/path\n",
-                    scene.m_indices.size(), st.n_nodes, st.bvh_depth, width, height, done, depth, secs,
+        std::printf("%zu triangles, %u BVH nodes (depth %u, built on the %s in %.1f ms), %ux%u, %u spp, depth %u: %.3f s, "
+                    "%.1f Mpaths/s, %.2f segments/path\n",
+                    scene.m_indices.size(), st.n_nodes, st.bvh_depth, st.bvh_builder ? "device" : "host", st.bvh_build_ms,
+                    width, height, done, depth, secs,
                     new_paths / secs / 1e6, new_paths > 0 ? static_cast<double>(st.segments) / new_paths : 0.0);
         if (!write_ppm(out, renderer.tonemapped(), width, height)) {
             std::fprintf(stderr, "cannot write %s\n", out.c_str());

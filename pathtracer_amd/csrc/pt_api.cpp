@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "bvh.h"
+#include "bvh_device.h"
 #include "camera.h"
 #include "device_types.h"
 #include "kernels.h"
@@ -123,6 +124,7 @@ struct pt_renderer {
     uint32_t region_size_env = 0;             // set through the environment (experiments)
     uint64_t scene_hash = 0;                  // FNV-1a over the scene arrays (checkpoint compatibility)
     uint8_t *d_rgba8 = nullptr;               // emulated 8-bit accumulation texture (cfg.emulate_rgba8)
+    uint32_t bvh_builder = 0;                 // the builder that made the tree (0 host, 1 device)
     bool scene_in_lds = true;                 // extend keeps nodes (and triangles) in LDS when they fit
     unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics [12] hits shaded [13] shade batches
 
@@ -404,23 +406,71 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
             ids[3 * static_cast<size_t>(t) + k] = static_cast<uint32_t>(f);
         }
 
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> int {
+        PT_HIP(hipMalloc(dst, std::max<size_t>(bytes, 64)));
+        if (bytes) PT_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return PT_OK;
+    };
+    int rc;
+    if ((rc = upload(&r->d_materials, sc->materials, static_cast<size_t>(sc->n_materials) * 32))) return rc;
+
     const double t0 = now_ms();
     pt::Bvh bvh;
-    if (r->cfg.use_bvh) {
-        pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
-        if (bvh.depth > 64) return fail(PT_ERR_STATE, "BVH deeper than the largest traversal stack");
+    const bool device_build = r->cfg.use_bvh && r->cfg.bvh_builder == 1u && T > 0;
+    float bounds_lo[3], bounds_hi[3];
+    if (device_build) {
+        // The triangles go up as they are; the tree is made where the renderer will read it.
+        void *d_vertices = nullptr, *d_ids = nullptr, *d_map = nullptr;
+        auto drop = [&]() {
+            (void)hipFree(d_vertices);
+            (void)hipFree(d_ids);
+            (void)hipFree(d_map);
+        };
+        if ((rc = upload(&d_vertices, sc->vertices, static_cast<size_t>(sc->n_vertices) * 12)) ||
+            (rc = upload(&d_ids, ids.data(), ids.size() * 4)) ||
+            (rc = upload(&d_map, sc->material_map, static_cast<size_t>(T) * 4))) {
+            drop();
+            return rc;
+        }
+        pt::DeviceBvhParams params;
+        params.leaf_max = pt::bvh_leaf_max();
+        params.traversal_cost = pt::bvh_traversal_cost();
+        pt::DeviceBvh built;
+        std::string why;
+        if (!pt::build_bvh_device(static_cast<const float *>(d_vertices), static_cast<const uint32_t *>(d_ids), T, params,
+                                  r->stream, &built, &why)) {
+            drop();
+            return fail(PT_ERR_STATE, why);
+        }
+        pt::mark_triangle_classes(built.d_triangles, T, static_cast<const uint32_t *>(d_map),
+                                  static_cast<const float *>(r->d_materials), sc->n_materials, r->stream);
+        const hipError_t e = hipStreamSynchronize(r->stream);
+        drop();
+        r->d_nodes = built.d_nodes;
+        r->d_tris = built.d_triangles;
+        if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("device BVH build: ") + hipGetErrorString(e));
+        r->n_nodes = built.n_nodes;
+        r->bvh_depth = built.depth;
+        r->sah_cost = built.sah_cost;
+        for (int a = 0; a < 3; ++a) bounds_lo[a] = built.bounds_lo[a], bounds_hi[a] = built.bounds_hi[a];
     } else {
-        // Scan mode: triangle records in the reference's order, no tree.
         pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
-        std::vector<pt::BvhTriangle> ordered(T);
-        for (const pt::BvhTriangle &tri : bvh.triangles) ordered[tri.original] = tri;
-        bvh.triangles.swap(ordered);
+        if (r->cfg.use_bvh) {
+            if (bvh.depth > 64) return fail(PT_ERR_STATE, "BVH deeper than the largest traversal stack");
+        } else {
+            // Scan mode: triangle records in the reference's order, no tree.
+            std::vector<pt::BvhTriangle> ordered(T);
+            for (const pt::BvhTriangle &tri : bvh.triangles) ordered[tri.original] = tri;
+            bvh.triangles.swap(ordered);
+        }
+        r->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
+        r->bvh_depth = bvh.depth;
+        r->sah_cost = bvh.sah_cost;
+        for (int a = 0; a < 3; ++a) bounds_lo[a] = bvh.bounds_lo[a], bounds_hi[a] = bvh.bounds_hi[a];
     }
     r->bvh_build_ms = now_ms() - t0;
-    r->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
-    r->bvh_depth = bvh.depth;
-    r->sah_cost = bvh.sah_cost;
-    r->stack_entries = std::max<uint32_t>(4, (bvh.depth + 3u) & ~3u);  // LDS stack: one entry per inner level, in fours
+    r->bvh_builder = device_build ? 1u : 0u;
+    r->stack_entries = std::max<uint32_t>(4, (r->bvh_depth + 3u) & ~3u);  // LDS stack: one entry per inner level, in fours
 
     std::vector<pt::ShadeTriangle> shade(T);
     for (uint32_t t = 0; t < T; ++t) {
@@ -463,27 +513,22 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
     }
 
     const double t1 = now_ms();
-    auto upload = [&](void **dst, const void *src, size_t bytes) -> int {
-        PT_HIP(hipMalloc(dst, std::max<size_t>(bytes, 64)));
-        if (bytes) PT_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
-        return PT_OK;
-    };
-    int rc;
-    if ((rc = upload(&r->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(pt::BvhNode)))) return rc;
-    // Sorting hint for the shade kernel: bit 30 of a record's triangle index marks surfaces that are not
-    // purely diffuse (scene.h material model: metallic > 0 or roughness < 1 reach the microfacet lobes).
-    for (pt::BvhTriangle &tri : bvh.triangles) {
-        const uint32_t m = sc->material_map[tri.original];
-        bool diffuse = false;
-        if (m < sc->n_materials) {
-            const float *mat = sc->materials + 8 * static_cast<size_t>(m);
-            diffuse = mat[4] <= 0.f && mat[3] >= 1.f;  // metallic, roughness
+    if (!device_build) {
+        if ((rc = upload(&r->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(pt::BvhNode)))) return rc;
+        // Sorting hint for the shade kernel: bit 30 of a record's triangle index marks surfaces that are not
+        // purely diffuse (scene.h material model: metallic > 0 or roughness < 1 reach the microfacet lobes).
+        for (pt::BvhTriangle &tri : bvh.triangles) {
+            const uint32_t m = sc->material_map[tri.original];
+            bool diffuse = false;
+            if (m < sc->n_materials) {
+                const float *mat = sc->materials + 8 * static_cast<size_t>(m);
+                diffuse = mat[4] <= 0.f && mat[3] >= 1.f;  // metallic, roughness
+            }
+            if (!diffuse) tri.original |= pt::kHitClassBit;
         }
-        if (!diffuse) tri.original |= pt::kHitClassBit;
+        if ((rc = upload(&r->d_tris, bvh.triangles.data(), bvh.triangles.size() * sizeof(pt::BvhTriangle)))) return rc;
     }
-    if ((rc = upload(&r->d_tris, bvh.triangles.data(), bvh.triangles.size() * sizeof(pt::BvhTriangle)))) return rc;
     if ((rc = upload(&r->d_shade, shade.data(), shade.size() * sizeof(pt::ShadeTriangle)))) return rc;
-    if ((rc = upload(&r->d_materials, sc->materials, static_cast<size_t>(sc->n_materials) * 32))) return rc;
     if ((rc = upload(&r->d_lights, lights.data(), lights.size() * sizeof(pt::DeviceLight)))) return rc;
     r->upload_ms = now_ms() - t1;
 
@@ -496,7 +541,7 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
     r->view.n_materials = sc->n_materials;
     r->view.n_lights = sc->n_lights;
     float radius = 0.f;
-    for (int a = 0; a < 3; ++a) radius = std::max(radius, std::max(std::fabs(bvh.bounds_lo[a]), std::fabs(bvh.bounds_hi[a])));
+    for (int a = 0; a < 3; ++a) radius = std::max(radius, std::max(std::fabs(bounds_lo[a]), std::fabs(bounds_hi[a])));
     r->view.scene_radius = radius;
     return PT_OK;
 }
@@ -696,6 +741,7 @@ void pt_config_default(pt_config *cfg)
     cfg->iterations_per_batch = 0;
     cfg->profile = 0;
     cfg->emulate_rgba8 = 0;
+    cfg->bvh_builder = 0;
 }
 
 int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer **out)
@@ -1113,6 +1159,16 @@ int pt_sum_device_ptr(pt_renderer *r, void **dev_ptr)
     return PT_OK;
 }
 
+int pt_read_bvh(pt_renderer *r, float *nodes_host, float *triangles_host)
+{
+    PT_REQUIRE(r, "pt_read_bvh: null argument");
+    PT_HIP(hipStreamSynchronize(r->stream));
+    if (nodes_host && r->n_nodes) PT_HIP(hipMemcpy(nodes_host, r->d_nodes, static_cast<size_t>(r->n_nodes) * 64, hipMemcpyDeviceToHost));
+    if (triangles_host && r->view.n_triangles)
+        PT_HIP(hipMemcpy(triangles_host, r->d_tris, static_cast<size_t>(r->view.n_triangles) * 64, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 int pt_bvh_inspect(const pt_scene_desc *sc, pt_bvh_info *info)
 {
     PT_REQUIRE(sc && info, "pt_bvh_inspect: null argument");
@@ -1230,6 +1286,8 @@ int pt_get_stats(pt_renderer *r, pt_stats *s)
     for (int k = 0; k < 8; ++k) s->extend_diag[k] = c[4 + k];
     s->hits_shaded = c[12];
     s->shade_batches = c[13];
+    s->bvh_builder = r->bvh_builder;
+    s->reserved = 0;
     return PT_OK;
 }
 

@@ -21,7 +21,7 @@ public:
     Camera *m_camera;
 
     Renderer(Scene *scene, Camera *camera, uint32_t maxDepth = 10, float fovYDegrees = 19.5f, bool useBvh = true,
-             int device = -1)
+             int device = -1, bool buildBvhOnDevice = false)
         : m_scene(scene), m_camera(camera)
     {
         pt_scene_desc d;
@@ -42,6 +42,7 @@ public:
         cfg.max_depth = maxDepth;
         cfg.fov_y_degrees = fovYDegrees;
         cfg.use_bvh = useBvh ? 1 : 0;
+        cfg.bvh_builder = buildBvhOnDevice ? 1 : 0;
         cfg.device = device;
         check(pt_create(&d, &cfg, &m_handle));
         updateCamera();

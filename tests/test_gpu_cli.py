@@ -79,6 +79,10 @@ def test_cli_lights_camera_checkpoint_resume(tmp_path):
     assert np.array_equal(_read_pfm(tmp_path / "b.pfm"), a)
     assert (tmp_path / "a.ppm").read_bytes() == (tmp_path / "b.ppm").read_bytes()
 
+    log = _run(common + ["--spp", "12", "--bvh", "device", "--out", "c.ppm", "--pfm", "c.pfm"], tmp_path)
+    assert "built on the device" in log
+    assert np.array_equal(_read_pfm(tmp_path / "c.pfm"), a)  # same tree, same image
+
     dark = _run(["--scene", "room.obj", "--mtl-root", "./", "--width", "32", "--height", "32", "--spp", "2", "--no-light",
                  "--pfm", "d.pfm", "--out", "d.ppm"], tmp_path)
     assert "2 spp" in dark and not _read_pfm(tmp_path / "d.pfm").any()
