@@ -43,4 +43,11 @@ bool build_bvh_device(const float *d_vertices, const uint32_t *d_tri_vertex_ids,
 void mark_triangle_classes(void *d_triangles, uint32_t n_triangles, const uint32_t *d_material_map, const float *d_materials,
                            uint32_t n_materials, hipStream_t stream);
 
+// The per-triangle shading records (device_types.h ShadeTriangle, 80 bytes each) from the
+// scene arrays as the caller's Scene lays them out: d_indices 4 floats per triangle,
+// d_vertex_data 6 floats per corner.  d_out holds n_triangles records.
+void build_shade_records(const float *d_vertices, const uint32_t *d_tri_vertex_ids, const float *d_indices,
+                         const float *d_vertex_data, const uint32_t *d_material_map, uint32_t n_triangles, void *d_out,
+                         hipStream_t stream);
+
 }  // namespace pt

@@ -8,10 +8,11 @@
 //
 // One level = the nodes created by the level before, contiguous in the node
 // array.  A node of up to kSmall triangles is handled by one wave: triangles in
-// LDS, one lane per (axis, bin), partition by ballot.  Larger nodes are binned by
-// a kernel over triangle positions (per-block LDS tables flushed with atomic
-// min / max on order-preserving integer images of the floats), split by the same
-// per-node wave, and partitioned by a second kernel over positions.  Children are
+// LDS, one lane per (axis, bin), partition by ballot.  Larger nodes are cut into
+// chunks of 1024 triangle positions: a block bins its chunk in LDS and flushes the
+// table with atomic min / max on order-preserving integer images of the floats,
+// the per-node wave picks the split from the table, and a second kernel over the
+// chunks moves the triangles, one atomic per block and side.  Children are
 // compacted behind a prefix sum so that the node array stays in breadth-first
 // order, which the final numbering relies on.
 #include "bvh_device.h"
@@ -172,11 +173,10 @@ __global__ void k_root_finish(const uint32_t *__restrict__ root_enc, uint32_t n,
     nodes[0] = r;
 }
 
-// ------------------------------------------------------------------ large nodes: binning over positions
+// ------------------------------------------------------------------ large nodes: binning by chunk
 
-__device__ __forceinline__ void bin_words(const float4 lo, const float4 hi, int a, uint32_t w[12])
+__device__ __forceinline__ void bin_words(const float4 lo, const float4 hi, uint32_t w[12])
 {
-    (void)a;
     const float cx = 0.5f * lo.x + 0.5f * hi.x, cy = 0.5f * lo.y + 0.5f * hi.y, cz = 0.5f * lo.z + 0.5f * hi.z;
     w[0] = ~enc(lo.x), w[1] = ~enc(lo.y), w[2] = ~enc(lo.z);
     w[3] = enc(hi.x), w[4] = enc(hi.y), w[5] = enc(hi.z);
@@ -184,68 +184,74 @@ __device__ __forceinline__ void bin_words(const float4 lo, const float4 hi, int 
     w[9] = enc(cx), w[10] = enc(cy), w[11] = enc(cz);
 }
 
-// Every triangle of a node of this level with more than kSmall triangles is added to
-// the node's 3 x 16 bins.  A block whose positions all belong to one such node (the
-// rule at the top of the tree) collects them in LDS first.
-__global__ void __launch_bounds__(256) k_bin_large(const NodeRec *__restrict__ nodes, uint32_t lvl_start,
-                                                    const uint32_t *__restrict__ owner, const float4 *__restrict__ cur,
-                                                    uint32_t n, uint32_t *__restrict__ gbins)
+// The large nodes of a level (more than kSmall triangles) are cut into chunks of kChunk
+// positions, none of which crosses a node boundary: chunk_start[s] = first chunk of the
+// node in slot s (exclusive prefix sums of the chunk counts), slot_node[s] = that node.
+struct ChunkOfBlock {
+    uint32_t node, slot, begin, end;
+};
+__device__ __forceinline__ ChunkOfBlock chunk_of_block(const NodeRec *__restrict__ nodes, const uint32_t *__restrict__ slot_node,
+                                                       const uint32_t *__restrict__ chunk_start, uint32_t n_large)
+{
+    // last slot whose first chunk is <= blockIdx.x
+    uint32_t lo = 0, hi = n_large;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunk_start[mid] <= blockIdx.x)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    ChunkOfBlock c;
+    c.slot = lo;
+    c.node = slot_node[lo];
+    const uint32_t first = nodes[c.node].begin, count = nodes[c.node].count;
+    c.begin = first + (blockIdx.x - chunk_start[lo]) * kChunk;
+    c.end = c.begin + kChunk < first + count ? c.begin + kChunk : first + count;
+    return c;
+}
+
+__global__ void __launch_bounds__(256) k_chunk_counts(const NodeRec *__restrict__ nodes, const uint32_t *__restrict__ slot_node,
+                                                       uint32_t n_large, uint32_t *__restrict__ chunks)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s < n_large) chunks[s] = (nodes[slot_node[s]].count + kChunk - 1u) / kChunk;
+}
+
+// Every triangle of a large node is added to the node's 3 x 16 bins: per chunk in LDS
+// first, then one atomic per touched word of the node's table.
+__global__ void __launch_bounds__(256) k_bin_large(const NodeRec *__restrict__ nodes, const uint32_t *__restrict__ slot_node,
+                                                    const uint32_t *__restrict__ chunk_start, uint32_t n_large,
+                                                    const float4 *__restrict__ cur, uint32_t *__restrict__ gbins)
 {
     __shared__ uint32_t s[kNodeBinWords];
-    const uint32_t base = blockIdx.x * kChunk;
-    const uint32_t end = base + kChunk < n ? base + kChunk : n;
-    const uint32_t o_first = owner[base], o_last = owner[end - 1u];
-    if (o_first == o_last) {
-        // a node's positions are contiguous, so every position in between has the same owner
-        if (o_first < lvl_start) return;
-        const NodeRec nd = nodes[o_first];
-        if (nd.count <= kSmall) return;
-        for (uint32_t w = threadIdx.x; w < kNodeBinWords; w += 256u) s[w] = 0u;
-        __syncthreads();
-        for (uint32_t pos = base + threadIdx.x; pos < end; pos += 256u) {
-            const float4 lo = cur[2 * static_cast<size_t>(pos)], hi = cur[2 * static_cast<size_t>(pos) + 1];
-            uint32_t w[12];
-            bin_words(lo, hi, 0, w);
-            for (int a = 0; a < 3; ++a) {
-                const float ext = nd.chi[a] - nd.clo[a];
-                if (!(ext > 0.f)) continue;
-                const float k = kBins / ext;
-                const float c = 0.5f * sel3(lo.x, lo.y, lo.z, a) + 0.5f * sel3(hi.x, hi.y, hi.z, a);
-                uint32_t *t = s + (a * kBins + bin_of(c, nd.clo[a], k)) * kBinWords;
-                for (int i = 0; i < 12; ++i) atomicMax(&t[i], w[i]);
-                atomicAdd(&t[12], 1u);
-            }
-        }
-        __syncthreads();
-        uint32_t *g = gbins + static_cast<size_t>(nd.slot) * kNodeBinWords;
-        for (uint32_t w = threadIdx.x; w < kNodeBinWords; w += 256u) {
-            const uint32_t v = s[w];
-            if (v == 0u) continue;
-            if (w % kBinWords == 12u)
-                atomicAdd(&g[w], v);
-            else
-                atomicMax(&g[w], v);
-        }
-        return;
-    }
-    for (uint32_t pos = base + threadIdx.x; pos < end; pos += 256u) {
-        const uint32_t o = owner[pos];
-        if (o < lvl_start) continue;
-        const NodeRec nd = nodes[o];
-        if (nd.count <= kSmall) continue;
+    const ChunkOfBlock ch = chunk_of_block(nodes, slot_node, chunk_start, n_large);
+    const NodeRec nd = nodes[ch.node];
+    for (uint32_t w = threadIdx.x; w < kNodeBinWords; w += 256u) s[w] = 0u;
+    __syncthreads();
+    for (uint32_t pos = ch.begin + threadIdx.x; pos < ch.end; pos += 256u) {
         const float4 lo = cur[2 * static_cast<size_t>(pos)], hi = cur[2 * static_cast<size_t>(pos) + 1];
         uint32_t w[12];
-        bin_words(lo, hi, 0, w);
-        uint32_t *g = gbins + static_cast<size_t>(nd.slot) * kNodeBinWords;
+        bin_words(lo, hi, w);
         for (int a = 0; a < 3; ++a) {
             const float ext = nd.chi[a] - nd.clo[a];
             if (!(ext > 0.f)) continue;
             const float k = kBins / ext;
             const float c = 0.5f * sel3(lo.x, lo.y, lo.z, a) + 0.5f * sel3(hi.x, hi.y, hi.z, a);
-            uint32_t *t = g + (a * kBins + bin_of(c, nd.clo[a], k)) * kBinWords;
+            uint32_t *t = s + (a * kBins + bin_of(c, nd.clo[a], k)) * kBinWords;
             for (int i = 0; i < 12; ++i) atomicMax(&t[i], w[i]);
             atomicAdd(&t[12], 1u);
         }
+    }
+    __syncthreads();
+    uint32_t *g = gbins + static_cast<size_t>(ch.slot) * kNodeBinWords;
+    for (uint32_t w = threadIdx.x; w < kNodeBinWords; w += 256u) {
+        const uint32_t v = s[w];
+        if (v == 0u) continue;
+        if (w % kBinWords == 12u)
+            atomicAdd(&g[w], v);
+        else
+            atomicMax(&g[w], v);
     }
 }
 
@@ -482,72 +488,55 @@ __global__ void __launch_bounds__(64) k_split_nodes(NodeRec *__restrict__ nodes,
     }
 }
 
-// ------------------------------------------------------------------ large nodes: partition over positions
+// ------------------------------------------------------------------ large nodes: partition by chunk
 
-__global__ void __launch_bounds__(256) k_partition_large(const NodeRec *__restrict__ nodes, uint32_t lvl_start,
-                                                          const uint32_t *__restrict__ owner, const float4 *__restrict__ cur,
-                                                          float4 *__restrict__ nxt, uint32_t n, SplitRec *__restrict__ splits)
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *total, uint32_t *s_wave);
+
+// The triangles of a chunk of a large node that is split move to their side of the node's
+// range in the other buffer: the block counts its left and right triangles, reserves a run
+// on each side with one atomic, and fills the two runs in position order.
+__global__ void __launch_bounds__(256) k_partition_large(const NodeRec *__restrict__ nodes, const uint32_t *__restrict__ slot_node,
+                                                          const uint32_t *__restrict__ chunk_start, uint32_t n_large,
+                                                          const float4 *__restrict__ cur, float4 *__restrict__ nxt,
+                                                          SplitRec *__restrict__ splits)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t base = blockIdx.x * kChunk;
-    for (uint32_t q = 0; q < kChunk; q += 256u) {
-        const uint32_t pos = base + q + threadIdx.x;
-        bool act = false, left = false;
-        uint32_t o = 0, slot = 0;
-        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-        SplitRec sp{};
-        if (pos < n) {
-            o = owner[pos];
-            if (o >= lvl_start && nodes[o].count > kSmall) {
-                slot = nodes[o].slot;
-                sp = splits[slot];
-                if (sp.axis >= 0) {
-                    act = true;
-                    lo = cur[2 * static_cast<size_t>(pos)], hi = cur[2 * static_cast<size_t>(pos) + 1];
-                    const float c = 0.5f * sel3(lo.x, lo.y, lo.z, sp.axis) + 0.5f * sel3(hi.x, hi.y, hi.z, sp.axis);
-                    left = bin_of(c, sp.lo, sp.k) <= sp.bin;
-                }
-            }
-        }
-        const unsigned long long am = __ballot(act);
-        if (am == 0ull) continue;
-        const int leader = __ffsll(static_cast<long long>(am)) - 1;
-        const uint32_t o0 = __shfl(o, leader);
-        uint32_t dst = 0;
-        if (__ballot(act && o != o0) == 0ull) {
-            // one node for the whole wave: one atomic per side
-            const unsigned long long ml = __ballot(act && left), mr = __ballot(act && !left);
-            uint32_t bl = 0, br = 0;
-            if (static_cast<int>(lane) == leader) {
-                if (ml) bl = atomicAdd(&splits[slot].taken_left, static_cast<uint32_t>(__popcll(ml)));
-                if (mr) br = atomicAdd(&splits[slot].taken_right, static_cast<uint32_t>(__popcll(mr)));
-            }
-            bl = __shfl(bl, leader), br = __shfl(br, leader);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            dst = left ? sp.begin + bl + static_cast<uint32_t>(__popcll(ml & below))
-                       : sp.begin + sp.n_left + br + static_cast<uint32_t>(__popcll(mr & below));
-        } else if (act) {
-            dst = left ? sp.begin + atomicAdd(&splits[slot].taken_left, 1u)
-                       : sp.begin + sp.n_left + atomicAdd(&splits[slot].taken_right, 1u);
-        }
-        if (act) {
-            nxt[2 * static_cast<size_t>(dst)] = lo;
-            nxt[2 * static_cast<size_t>(dst) + 1] = hi;
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base[2];
+    const ChunkOfBlock ch = chunk_of_block(nodes, slot_node, chunk_start, n_large);
+    const SplitRec sp = splits[ch.slot];
+    if (sp.axis < 0) return;
+    constexpr uint32_t kPer = kChunk / 256u;
+    float4 lo[kPer], hi[kPer];
+    bool in[kPer], left[kPer];
+    uint32_t n_l = 0, n_r = 0;
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const uint32_t pos = ch.begin + threadIdx.x * kPer + q;
+        in[q] = pos < ch.end;
+        left[q] = false;
+        if (in[q]) {
+            lo[q] = cur[2 * static_cast<size_t>(pos)], hi[q] = cur[2 * static_cast<size_t>(pos) + 1];
+            const float c = 0.5f * sel3(lo[q].x, lo[q].y, lo[q].z, sp.axis) + 0.5f * sel3(hi[q].x, hi[q].y, hi[q].z, sp.axis);
+            left[q] = bin_of(c, sp.lo, sp.k) <= sp.bin;
+            n_l += left[q] ? 1u : 0u;
+            n_r += left[q] ? 0u : 1u;
         }
     }
-}
-
-// owner[pos] = the deepest node made so far that holds position pos
-__global__ void __launch_bounds__(256) k_update_owner(const NodeRec *__restrict__ nodes, uint32_t lvl_start,
-                                                       uint32_t *__restrict__ owner, uint32_t n)
-{
-    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    if (pos >= n) return;
-    const uint32_t o = owner[pos];
-    if (o < lvl_start) return;
-    const int32_t l = nodes[o].left;
-    if (l < 0) return;
-    owner[pos] = pos < nodes[l + 1].begin ? static_cast<uint32_t>(l) : static_cast<uint32_t>(l) + 1u;
+    uint32_t total_l, total_r;
+    uint32_t at_l = block_exclusive_scan(n_l, &total_l, s_wave);
+    uint32_t at_r = block_exclusive_scan(n_r, &total_r, s_wave);
+    if (threadIdx.x == 0) {
+        s_base[0] = total_l ? atomicAdd(&splits[ch.slot].taken_left, total_l) : 0u;
+        s_base[1] = total_r ? atomicAdd(&splits[ch.slot].taken_right, total_r) : 0u;
+    }
+    __syncthreads();
+    at_l += sp.begin + s_base[0];
+    at_r += sp.begin + sp.n_left + s_base[1];
+    for (uint32_t q = 0; q < kPer; ++q) {
+        if (!in[q]) continue;
+        const uint32_t dst = left[q] ? at_l++ : at_r++;
+        nxt[2 * static_cast<size_t>(dst)] = lo[q];
+        nxt[2 * static_cast<size_t>(dst) + 1] = hi[q];
+    }
 }
 
 // ------------------------------------------------------------------ exclusive prefix sum of 32-bit counts
@@ -626,14 +615,18 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
 __global__ void __launch_bounds__(256) k_compact_children(NodeRec *__restrict__ nodes, uint32_t lvl_start, uint32_t lvl_count,
                                                            uint32_t next_start, const NodeRec *__restrict__ child_scratch,
                                                            const uint32_t *__restrict__ flags,
-                                                           const uint32_t *__restrict__ rank, Counters *__restrict__ ctr)
+                                                           const uint32_t *__restrict__ rank, Counters *__restrict__ ctr,
+                                                           uint32_t *__restrict__ slot_node)
 {
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= lvl_count || flags[j] == 0u) return;
     const uint32_t dst = next_start + 2u * rank[j];
     for (uint32_t c = 0; c < 2u; ++c) {
         NodeRec r = child_scratch[2 * static_cast<size_t>(j) + c];
-        if (r.count > kSmall) r.slot = atomicAdd(&ctr->n_large_next, 1u);
+        if (r.count > kSmall) {
+            r.slot = atomicAdd(&ctr->n_large_next, 1u);
+            slot_node[r.slot] = dst + c;
+        }
         nodes[dst + c] = r;
     }
     nodes[lvl_start + j].left = static_cast<int32_t>(dst);
@@ -804,6 +797,32 @@ __global__ void __launch_bounds__(256) k_mark_classes(float4 *__restrict__ tris,
     }
 }
 
+// The shading record of every original triangle (device_types.h ShadeTriangle): corner
+// positions, the corner normals of vertex-data record int(indices.w) (pathtracer.frag.glsl:
+// 437,447-449) and the material index.
+__global__ void __launch_bounds__(256) k_shade_records(const float *__restrict__ vertices, const uint32_t *__restrict__ ids,
+                                                        const float *__restrict__ indices, const float *__restrict__ vertex_data,
+                                                        const uint32_t *__restrict__ material_map, uint32_t n,
+                                                        float4 *__restrict__ out)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    const float *v0 = vertices + 3 * static_cast<size_t>(ids[3 * static_cast<size_t>(t) + 0]);
+    const float *v1 = vertices + 3 * static_cast<size_t>(ids[3 * static_cast<size_t>(t) + 1]);
+    const float *v2 = vertices + 3 * static_cast<size_t>(ids[3 * static_cast<size_t>(t) + 2]);
+    const float wf = indices[4 * static_cast<size_t>(t) + 3];
+    const size_t data = (wf >= 0.f && wf < static_cast<float>(n)) ? static_cast<size_t>(wf) : t;
+    const float *n1 = vertex_data + 6 * (3 * data + 0);
+    const float *n2 = vertex_data + 6 * (3 * data + 1);
+    const float *n3 = vertex_data + 6 * (3 * data + 2);
+    float4 *o = out + 5 * static_cast<size_t>(t);
+    o[0] = make_float4(v0[0], v0[1], v0[2], n1[0]);
+    o[1] = make_float4(v1[0], v1[1], v1[2], n1[1]);
+    o[2] = make_float4(v2[0], v2[1], v2[2], n1[2]);
+    o[3] = make_float4(n2[0], n2[1], n2[2], __uint_as_float(material_map[t]));
+    o[4] = make_float4(n3[0], n3[1], n3[2], 0.f);
+}
+
 // ------------------------------------------------------------------ host side
 
 struct Buffers {
@@ -844,6 +863,15 @@ void mark_triangle_classes(void *d_triangles, uint32_t n_triangles, const uint32
                        static_cast<float4 *>(d_triangles), n_triangles, d_material_map, d_materials, n_materials);
 }
 
+void build_shade_records(const float *d_vertices, const uint32_t *d_tri_vertex_ids, const float *d_indices,
+                         const float *d_vertex_data, const uint32_t *d_material_map, uint32_t n_triangles, void *d_out,
+                         hipStream_t stream)
+{
+    if (n_triangles == 0) return;
+    hipLaunchKernelGGL(k_shade_records, dim3((n_triangles + 255u) / 256u), dim3(256), 0, stream, d_vertices, d_tri_vertex_ids,
+                       d_indices, d_vertex_data, d_material_map, n_triangles, static_cast<float4 *>(d_out));
+}
+
 #define PT_BVH_TRY(expr)                                                                        \
     do {                                                                                        \
         const hipError_t e_ = (expr);                                                           \
@@ -867,7 +895,7 @@ bool build_bvh_device(const float *d_vertices, const uint32_t *d_ids, uint32_t T
     }
     Buffers buf;
     float4 *prims[2] = {nullptr, nullptr};
-    uint32_t *owner = nullptr, *order = nullptr, *flags = nullptr, *rank = nullptr, *sums = nullptr, *gbins = nullptr;
+    uint32_t *slot_node = nullptr, *chunks = nullptr, *chunk_start = nullptr, *order = nullptr, *flags = nullptr, *rank = nullptr, *sums = nullptr, *gbins = nullptr;
     uint32_t *root_enc = nullptr, *d_total = nullptr, *sizes = nullptr, *index = nullptr, *root_size = nullptr;
     NodeRec *nodes = nullptr, *child_scratch = nullptr;
     SplitRec *splits = nullptr;
@@ -877,7 +905,7 @@ bool build_bvh_device(const float *d_vertices, const uint32_t *d_ids, uint32_t T
     const size_t max_large = static_cast<size_t>(T) / kSmall + 2;
     const uint32_t top = params.top_breadth_first;
     bool ok = buf.get(&prims[0], 2 * static_cast<size_t>(T)) && buf.get(&prims[1], 2 * static_cast<size_t>(T)) &&
-              buf.get(&owner, T) && buf.get(&order, T) && buf.get(&flags, max_nodes) && buf.get(&rank, max_nodes) &&
+              buf.get(&slot_node, max_large) && buf.get(&chunks, max_large) && buf.get(&chunk_start, max_large) && buf.get(&order, T) && buf.get(&flags, max_nodes) && buf.get(&rank, max_nodes) &&
               buf.get(&sums, max_nodes / kScanTile + 2) && buf.get(&gbins, max_large * kNodeBinWords) &&
               buf.get(&root_enc, 16) && buf.get(&d_total, 4) && buf.get(&sizes, max_nodes) && buf.get(&index, max_nodes) &&
               buf.get(&root_size, 2 * static_cast<size_t>(top) + 4) && buf.get(&nodes, max_nodes) &&
@@ -889,7 +917,8 @@ bool build_bvh_device(const float *d_vertices, const uint32_t *d_ids, uint32_t T
     }
 
     PT_BVH_TRY(hipMemsetAsync(root_enc, 0, 64, st));
-    PT_BVH_TRY(hipMemsetAsync(owner, 0, static_cast<size_t>(T) * 4, st));
+    PT_BVH_TRY(hipMemsetAsync(slot_node, 0, 4, st));   // the root is the large node in slot 0 ...
+    PT_BVH_TRY(hipMemsetAsync(chunk_start, 0, 4, st));  // ... and its chunks are all there are
     PT_BVH_TRY(hipMemsetAsync(ctr, 0, sizeof(Counters), st));
     hipLaunchKernelGGL(k_prims_init, dim3(std::min<uint32_t>(1024, blocks_for(T, 256))), dim3(256), 0, st, d_vertices, d_ids, T,
                        prims[0], root_enc);
@@ -901,23 +930,24 @@ bool build_bvh_device(const float *d_vertices, const uint32_t *d_ids, uint32_t T
     std::vector<Level> levels;
     uint32_t lvl_start = 0, lvl_count = 1, n_large = T > kSmall ? 1u : 0u, level = 0, depth = 0;
     int cur = 0;
-    const uint32_t pos_blocks = blocks_for(T, kChunk);
+    uint32_t n_chunks = blocks_for(T, kChunk);
     while (lvl_count > 0) {
         levels.push_back(Level{lvl_start, lvl_count});
         if (n_large) {
             PT_BVH_TRY(hipMemsetAsync(gbins, 0, static_cast<size_t>(n_large) * kNodeBinWords * 4, st));
-            hipLaunchKernelGGL(k_bin_large, dim3(pos_blocks), dim3(256), 0, st, nodes, lvl_start, owner, prims[cur], T, gbins);
+            hipLaunchKernelGGL(k_bin_large, dim3(n_chunks), dim3(256), 0, st, nodes, slot_node, chunk_start, n_large, prims[cur],
+                               gbins);
         }
         PT_BVH_TRY(hipMemsetAsync(&ctr->n_large_next, 0, 4, st));
         hipLaunchKernelGGL(k_split_nodes, dim3(lvl_count), dim3(64), 0, st, nodes, lvl_start, level, prims[cur], prims[cur ^ 1],
                            order, gbins, splits, child_scratch, flags, ctr, params.leaf_max, params.traversal_cost);
         if (n_large)
-            hipLaunchKernelGGL(k_partition_large, dim3(pos_blocks), dim3(256), 0, st, nodes, lvl_start, owner, prims[cur],
-                               prims[cur ^ 1], T, splits);
+            hipLaunchKernelGGL(k_partition_large, dim3(n_chunks), dim3(256), 0, st, nodes, slot_node, chunk_start, n_large,
+                               prims[cur], prims[cur ^ 1], splits);
         exclusive_scan(flags, lvl_count, rank, sums, d_total, st);
         const uint32_t next_start = lvl_start + lvl_count;
         hipLaunchKernelGGL(k_compact_children, dim3(blocks_for(lvl_count, 256)), dim3(256), 0, st, nodes, lvl_start, lvl_count,
-                           next_start, child_scratch, flags, rank, ctr);
+                           next_start, child_scratch, flags, rank, ctr, slot_node);
         uint32_t n_split = 0;
         Counters h{};
         PT_BVH_TRY(hipMemcpyAsync(&n_split, d_total, 4, hipMemcpyDeviceToHost, st));
@@ -936,8 +966,14 @@ bool build_bvh_device(const float *d_vertices, const uint32_t *d_ids, uint32_t T
             *error = "device BVH build: tree deeper than the traversal stack; use the host builder";
             return false;
         }
-        if (h.n_large_next)
-            hipLaunchKernelGGL(k_update_owner, dim3(blocks_for(T, 256)), dim3(256), 0, st, nodes, lvl_start, owner, T);
+        if (h.n_large_next) {
+            // the next level's chunk list
+            hipLaunchKernelGGL(k_chunk_counts, dim3(blocks_for(h.n_large_next, 256)), dim3(256), 0, st, nodes, slot_node,
+                               h.n_large_next, chunks);
+            exclusive_scan(chunks, h.n_large_next, chunk_start, sums, d_total, st);
+            PT_BVH_TRY(hipMemcpyAsync(&n_chunks, d_total, 4, hipMemcpyDeviceToHost, st));
+            PT_BVH_TRY(hipStreamSynchronize(st));
+        }
         lvl_start = next_start;
         lvl_count = 2u * n_split;
         n_large = h.n_large_next;

@@ -374,19 +374,34 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     return PT_OK;
 }
 
+// 64-bit FNV-1a over 8-byte words in four interleaved lanes (a byte-wise hash of a
+// gigabyte of scene data would take longer than building its tree), the tail byte-wise.
 uint64_t fnv1a(uint64_t h, const void *data, size_t bytes)
 {
+    constexpr uint64_t kPrime = 1099511628211ull;
     const unsigned char *p = static_cast<const unsigned char *>(data);
-    for (size_t i = 0; i < bytes; ++i) {
-        h ^= p[i];
-        h *= 1099511628211ull;
+    uint64_t lane[4] = {h, h ^ 0x9E3779B97F4A7C15ull, h ^ 0xC2B2AE3D27D4EB4Full, h ^ 0x165667B19E3779F9ull};
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, p + i, 32);
+        for (int k = 0; k < 4; ++k) lane[k] = (lane[k] ^ w[k]) * kPrime;
     }
-    return h;
+    for (; i < bytes; ++i) lane[0] = (lane[0] ^ p[i]) * kPrime;
+    uint64_t out = lane[0];
+    for (int k = 1; k < 4; ++k) out = (out ^ lane[k]) * kPrime;
+    return out;
 }
 
 int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
 {
     const uint32_t T = sc->n_triangles;
+    const bool timing = std::getenv("PT_TIMING") != nullptr;  // stage times of this function on stderr
+    double t_stage = now_ms();
+    auto stage = [&](const char *what) {
+        if (timing) std::fprintf(stderr, "upload_scene: %-28s %8.1f ms\n", what, now_ms() - t_stage);
+        t_stage = now_ms();
+    };
     {
         uint64_t h = 1469598103934665603ull;
         h = fnv1a(h, sc->vertices, static_cast<size_t>(sc->n_vertices) * 12);
@@ -397,6 +412,7 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
         h = fnv1a(h, sc->material_map, static_cast<size_t>(T) * 4);
         r->scene_hash = h;
     }
+    stage("scene hash");
     std::vector<uint32_t> ids(static_cast<size_t>(T) * 3);
     for (uint32_t t = 0; t < T; ++t)
         for (int k = 0; k < 3; ++k) {
@@ -406,6 +422,7 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
             ids[3 * static_cast<size_t>(t) + k] = static_cast<uint32_t>(f);
         }
 
+    stage("vertex indices");
     auto upload = [&](void **dst, const void *src, size_t bytes) -> int {
         PT_HIP(hipMalloc(dst, std::max<size_t>(bytes, 64)));
         if (bytes) PT_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
@@ -418,20 +435,33 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
     pt::Bvh bvh;
     const bool device_build = r->cfg.use_bvh && r->cfg.bvh_builder == 1u && T > 0;
     float bounds_lo[3], bounds_hi[3];
+    double device_upload_ms = 0.0;  // device builder: the scene arrays go up before the tree is made
     if (device_build) {
         // The triangles go up as they are; the tree is made where the renderer will read it.
-        void *d_vertices = nullptr, *d_ids = nullptr, *d_map = nullptr;
+        void *d_vertices = nullptr, *d_ids = nullptr, *d_map = nullptr, *d_indices = nullptr, *d_vertex_data = nullptr;
         auto drop = [&]() {
             (void)hipFree(d_vertices);
             (void)hipFree(d_ids);
             (void)hipFree(d_map);
+            (void)hipFree(d_indices);
+            (void)hipFree(d_vertex_data);
         };
         if ((rc = upload(&d_vertices, sc->vertices, static_cast<size_t>(sc->n_vertices) * 12)) ||
             (rc = upload(&d_ids, ids.data(), ids.size() * 4)) ||
-            (rc = upload(&d_map, sc->material_map, static_cast<size_t>(T) * 4))) {
+            (rc = upload(&d_map, sc->material_map, static_cast<size_t>(T) * 4)) ||
+            (rc = upload(&d_indices, sc->indices, static_cast<size_t>(T) * 16)) ||
+            (rc = upload(&d_vertex_data, sc->vertex_data, static_cast<size_t>(T) * 72))) {
             drop();
             return rc;
         }
+        if (hipMalloc(&r->d_shade, std::max<size_t>(static_cast<size_t>(T) * sizeof(pt::ShadeTriangle), 64)) != hipSuccess) {
+            drop();
+            return fail(PT_ERR_DEVICE, "out of device memory for the shading records");
+        }
+        device_upload_ms = now_ms() - t0;
+        pt::build_shade_records(static_cast<const float *>(d_vertices), static_cast<const uint32_t *>(d_ids),
+                                static_cast<const float *>(d_indices), static_cast<const float *>(d_vertex_data),
+                                static_cast<const uint32_t *>(d_map), T, r->d_shade, r->stream);
         pt::DeviceBvhParams params;
         params.leaf_max = pt::bvh_leaf_max();
         params.traversal_cost = pt::bvh_traversal_cost();
@@ -468,12 +498,13 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
         r->sah_cost = bvh.sah_cost;
         for (int a = 0; a < 3; ++a) bounds_lo[a] = bvh.bounds_lo[a], bounds_hi[a] = bvh.bounds_hi[a];
     }
-    r->bvh_build_ms = now_ms() - t0;
+    r->bvh_build_ms = now_ms() - t0 - device_upload_ms;
+    stage("BVH");
     r->bvh_builder = device_build ? 1u : 0u;
     r->stack_entries = std::max<uint32_t>(4, (r->bvh_depth + 3u) & ~3u);  // LDS stack: one entry per inner level, in fours
 
-    std::vector<pt::ShadeTriangle> shade(T);
-    for (uint32_t t = 0; t < T; ++t) {
+    std::vector<pt::ShadeTriangle> shade(device_build ? 0 : T);
+    for (uint32_t t = 0; t < static_cast<uint32_t>(shade.size()); ++t) {
         const float *v[3];
         for (int k = 0; k < 3; ++k) v[k] = sc->vertices + 3 * static_cast<size_t>(ids[3 * static_cast<size_t>(t) + k]);
         // The reference reads the normals of record int(indices.w) (frag:437,447-449).
@@ -512,6 +543,7 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
         lights[l].normal[2] = rec[4 + 10];
     }
 
+    stage("shading records, lights");
     const double t1 = now_ms();
     if (!device_build) {
         if ((rc = upload(&r->d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(pt::BvhNode)))) return rc;
@@ -528,9 +560,10 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
         }
         if ((rc = upload(&r->d_tris, bvh.triangles.data(), bvh.triangles.size() * sizeof(pt::BvhTriangle)))) return rc;
     }
-    if ((rc = upload(&r->d_shade, shade.data(), shade.size() * sizeof(pt::ShadeTriangle)))) return rc;
+    if (!device_build && (rc = upload(&r->d_shade, shade.data(), shade.size() * sizeof(pt::ShadeTriangle)))) return rc;
     if ((rc = upload(&r->d_lights, lights.data(), lights.size() * sizeof(pt::DeviceLight)))) return rc;
-    r->upload_ms = now_ms() - t1;
+    r->upload_ms = now_ms() - t1 + device_upload_ms;
+    stage("uploads");
 
     r->view.nodes = static_cast<const float4 *>(r->d_nodes);
     r->view.triangles = static_cast<const float4 *>(r->d_tris);
