@@ -50,13 +50,19 @@ def parse_args():
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--depth", type=int, default=8)
     p.add_argument("--spp-per-step", type=int, default=16)
+    p.add_argument("--lattice", type=int, default=0,
+                   help="instance the scene's shapes (all but its 10 room triangles) on an N^3 lattice")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary Veggie.obj measurement")
     return p.parse_args()
 
 
+LATTICE = 0  # --lattice N: the scene's furniture instanced N^3 times in its room (N = 19: 9.88 M triangles)
+
+
 def load_scene(pt, name):
-    return pt.Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", name + ".npz"))
+    scene = pt.Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", name + ".npz"))
+    return scene.instance_lattice(10, LATTICE) if LATTICE else scene
 
 
 def timed_run(pt, torch, dist, args, scene_name, rank, world, device, distributed):
@@ -157,7 +163,11 @@ def cpu_baseline(args, scene_name):
 
 
 def main():
+    global LATTICE
     args = parse_args()
+    if args.lattice:
+        # the CPU oracle scans every triangle per ray: no CPU leg on millions of triangles
+        LATTICE, args.no_cpu_baseline, args.no_extra = args.lattice, True, True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -256,13 +266,18 @@ def main():
             "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene}.obj {args.width}x{args.height}, max depth {args.depth}, "
+            "config": {"workload": f"{args.scene}.obj{f' instanced on a {LATTICE}^3 lattice' if LATTICE else ''} "
+                                   f"{args.width}x{args.height}, max depth {args.depth}, "
                                    f"{args.spp_per_step} spp per step per GPU, default camera and light",
                        "paths_per_step": n_pixels * args.spp_per_step * world, "parallelism": f"sample-partition x{world}"},
             "msegments_per_s": value * st["segments"] / max(1, st["paths"]),
             "segments_per_path": st["segments"] / max(1, st["paths"]),
             "gates": gates,
             "roofline": roofline,
+            # outside the timed region: the tree and the uploads of pt_create
+            "setup": {"triangles": st["n_triangles"], "bvh_nodes": st["n_nodes"], "bvh_depth": st["bvh_depth"],
+                      "bvh_builder": "device" if st["bvh_builder"] else "host", "bvh_build_ms": st["bvh_build_ms"],
+                      "upload_ms": st["upload_ms"]},
         }
         timing = os.path.join(ROOT, "tests", "golden", "llvmpipe", "llvmpipe_timing.json")
         if os.path.exists(timing):

@@ -72,12 +72,14 @@ typedef struct {
                                       samples and all.  Single renderer only (the running
                                       average is not a sum and cannot be partitioned).   */
     uint32_t bvh_builder;          /* 0: the tree is built on the host (threads) and uploaded;
-                                      1: it is built on the GPU from the uploaded triangles.
-                                      Both make the same tree; the device build takes
-                                      milliseconds where the host takes seconds on ten
-                                      million triangles.  pt_create fails with the device
-                                      builder on input that needs the host builder's
-                                      object-median fall-back (see pt_last_error).        */
+                                      1: it is built on the GPU from the uploaded triangles;
+                                      2 (default): on the GPU from 65536 triangles up, on
+                                      the host below that and for input the device builder
+                                      declines.  Both make the same tree; the device build
+                                      takes milliseconds where the host takes seconds on ten
+                                      million triangles.  With 1, pt_create fails on input
+                                      that needs the host builder's object-median fall-back
+                                      (see pt_last_error).                                  */
 } pt_config;
 
 typedef struct {

@@ -371,7 +371,7 @@ class Renderer:
     def __init__(self, scene: Scene, camera: Optional[Camera] = None, *, max_depth: int = 10,
                  fov_y_degrees: float = 19.5, device: int = -1, use_bvh: bool = True,
                  iterations_per_batch: int = 0, profile: int = 0, emulate_rgba8: bool = False,
-                 bvh_builder: str = "host"):
+                 bvh_builder: str = "auto"):
         self.scene = scene
         self.camera = camera if camera is not None else Camera()
         w, h = self.camera.resolution
@@ -385,9 +385,9 @@ class Renderer:
         cfg.iterations_per_batch = iterations_per_batch
         cfg.profile = int(profile)  # bit 0: per-launch HIP-event timing; bit 1: traversal counters
         cfg.emulate_rgba8 = 1 if emulate_rgba8 else 0
-        if bvh_builder not in ("host", "device"):
-            raise ValueError("bvh_builder is 'host' or 'device'")
-        cfg.bvh_builder = 1 if bvh_builder == "device" else 0
+        if bvh_builder not in ("host", "device", "auto"):
+            raise ValueError("bvh_builder is 'host', 'device' or 'auto'")
+        cfg.bvh_builder = {"host": 0, "device": 1, "auto": 2}[bvh_builder]
         self.config = cfg
         self._h = _vp()
         d = scene.desc()

@@ -433,19 +433,25 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
 
     const double t0 = now_ms();
     pt::Bvh bvh;
-    const bool device_build = r->cfg.use_bvh && r->cfg.bvh_builder == 1u && T > 0;
+    // bvh_builder 2: the device builder for scenes large enough to repay its launches, and the
+    // host builder for input the device builder declines.
+    constexpr uint32_t kAutoDeviceTriangles = 1u << 16;
+    const bool automatic = r->cfg.bvh_builder == 2u;
+    bool device_build = r->cfg.use_bvh && T > 0 && (r->cfg.bvh_builder == 1u || (automatic && T >= kAutoDeviceTriangles));
     float bounds_lo[3], bounds_hi[3];
     double device_upload_ms = 0.0;  // device builder: the scene arrays go up before the tree is made
+    void *d_vertices = nullptr, *d_ids = nullptr, *d_map = nullptr, *d_indices = nullptr, *d_vertex_data = nullptr;
+    auto drop = [&]() {
+        (void)hipFree(d_vertices);
+        (void)hipFree(d_ids);
+        (void)hipFree(d_map);
+        (void)hipFree(d_indices);
+        (void)hipFree(d_vertex_data);
+        d_vertices = d_ids = d_map = d_indices = d_vertex_data = nullptr;
+    };
+    pt::DeviceBvh built;
     if (device_build) {
         // The triangles go up as they are; the tree is made where the renderer will read it.
-        void *d_vertices = nullptr, *d_ids = nullptr, *d_map = nullptr, *d_indices = nullptr, *d_vertex_data = nullptr;
-        auto drop = [&]() {
-            (void)hipFree(d_vertices);
-            (void)hipFree(d_ids);
-            (void)hipFree(d_map);
-            (void)hipFree(d_indices);
-            (void)hipFree(d_vertex_data);
-        };
         if ((rc = upload(&d_vertices, sc->vertices, static_cast<size_t>(sc->n_vertices) * 12)) ||
             (rc = upload(&d_ids, ids.data(), ids.size() * 4)) ||
             (rc = upload(&d_map, sc->material_map, static_cast<size_t>(T) * 4)) ||
@@ -465,13 +471,19 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
         pt::DeviceBvhParams params;
         params.leaf_max = pt::bvh_leaf_max();
         params.traversal_cost = pt::bvh_traversal_cost();
-        pt::DeviceBvh built;
         std::string why;
         if (!pt::build_bvh_device(static_cast<const float *>(d_vertices), static_cast<const uint32_t *>(d_ids), T, params,
                                   r->stream, &built, &why)) {
             drop();
-            return fail(PT_ERR_STATE, why);
+            if (!automatic) return fail(PT_ERR_STATE, why);
+            (void)hipStreamSynchronize(r->stream);
+            (void)hipFree(r->d_shade);
+            r->d_shade = nullptr;
+            device_build = false;
+            device_upload_ms = 0.0;
         }
+    }
+    if (device_build) {
         pt::mark_triangle_classes(built.d_triangles, T, static_cast<const uint32_t *>(d_map),
                                   static_cast<const float *>(r->d_materials), sc->n_materials, r->stream);
         const hipError_t e = hipStreamSynchronize(r->stream);
@@ -483,7 +495,8 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
         r->bvh_depth = built.depth;
         r->sah_cost = built.sah_cost;
         for (int a = 0; a < 3; ++a) bounds_lo[a] = built.bounds_lo[a], bounds_hi[a] = built.bounds_hi[a];
-    } else {
+    }
+    if (!device_build) {
         pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
         if (r->cfg.use_bvh) {
             if (bvh.depth > 64) return fail(PT_ERR_STATE, "BVH deeper than the largest traversal stack");
@@ -774,7 +787,7 @@ void pt_config_default(pt_config *cfg)
     cfg->iterations_per_batch = 0;
     cfg->profile = 0;
     cfg->emulate_rgba8 = 0;
-    cfg->bvh_builder = 0;
+    cfg->bvh_builder = 2;
 }
 
 int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer **out)

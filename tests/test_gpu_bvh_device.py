@@ -78,6 +78,34 @@ def test_coinciding_centroids(pt):
     pt.Renderer(scene, pt.Camera(resolution=(32, 32)), bvh_builder="host").close()
 
 
+def test_automatic_choice_and_fall_back(pt):
+    rng = np.random.default_rng(3)
+    c = rng.uniform(-4, 4, (70000, 1, 3)).astype(np.float32)
+    soup = c + rng.uniform(-0.05, 0.05, (70000, 3, 3)).astype(np.float32)
+    cam = pt.Camera(resolution=(32, 32))
+    small = pt.Renderer(pt.Scene.from_arrays(**scene_arrays("Box")), cam)
+    assert small.stats()["bvh_builder"] == 0  # not worth the launches
+    small.close()
+    big = pt.Renderer(pt.Scene.from_arrays(**_soup(soup)), cam)
+    assert big.stats()["bvh_builder"] == 1
+    nodes_auto, tris_auto = big.read_bvh()
+    big.close()
+    # the same soup with 300 copies of one triangle in it: the device builder declines, the host builder takes over
+    same = np.tile(np.array([[[0.25, 0.25, 0], [0.75, 0.25, 0], [0.25, 0.5, 0.125]]], np.float32), (300, 1, 1))
+    r = pt.Renderer(pt.Scene.from_arrays(**_soup(np.concatenate([soup, same]))), cam)
+    st = r.stats()
+    assert st["bvh_builder"] == 0 and st["n_triangles"] == 70300
+    ids = r.read_hit_ids(0)[0]
+    r.close()
+    assert ids.shape == (32, 32)
+    host = pt.Renderer(pt.Scene.from_arrays(**_soup(soup)), cam, bvh_builder="host")
+    nodes_host, tris_host = host.read_bvh()
+    host.close()
+    assert np.array_equal(nodes_auto[:, :12], nodes_host[:, :12])
+    assert np.array_equal(nodes_auto[:, 12:].view(np.int32), nodes_host[:, 12:].view(np.int32))
+    assert np.array_equal(tris_auto.view(np.uint32), tris_host.view(np.uint32))
+
+
 def test_random_soup_same_tree(pt):
     rng = np.random.default_rng(11)
     c = rng.uniform(-4, 4, (20000, 1, 3)).astype(np.float32)
