@@ -237,7 +237,8 @@ def main():
         # HBM bytes per launch and VALU figures of the same command under rocprofv3 --pmc (separate passes,
         # FETCH_SIZE doubled for gfx950), kept with the profile summaries.
         pmc, traffic = {}, None
-        pmc_file = os.path.join(ROOT, "profiles", f"pmc_{args.scene}_{args.width}x{args.height}.json")
+        tag = f"{args.scene}_lattice{LATTICE}" if LATTICE else args.scene
+        pmc_file = os.path.join(ROOT, "profiles", f"pmc_{tag}_{args.width}x{args.height}.json")
         if os.path.exists(pmc_file):
             allk = json.load(open(pmc_file))
             for name, m in allk.items():
