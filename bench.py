@@ -102,12 +102,14 @@ def timed_run(pt, torch, dist, args, scene_name, rank, world, device, distribute
     return dt, r
 
 
-def kernel_profile(pt, args, scene_name, device, rank, world):
-    """Same workload with every launch bracketed by HIP events on the
-    renderer's own stream (pt_config.profile)."""
+def kernel_profile(pt, args, scene_name, device, rank, world, batch_streams=2, counters=True):
+    """Same workload with every launch bracketed by HIP events on the stream it is
+    launched on (pt_config.profile).  batch_streams = 2: as in the timed run, the
+    kernels of two batches overlap and a launch's duration includes what it shares
+    with the other batch; 1: every kernel alone on the GPU."""
     cam = pt.Camera(resolution=(args.width, args.height))
     r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
-                    iterations_per_batch=args.spp_per_step, profile=1)
+                    iterations_per_batch=args.spp_per_step, profile=1, batch_streams=batch_streams)
     r.set_partition(rank, world)
     r.draw(args.spp_per_step)  # warm
     r.synchronize()
@@ -117,6 +119,8 @@ def kernel_profile(pt, args, scene_name, device, rank, world):
         r.draw(args.spp_per_step)
     st = r.stats()
     r.close()
+    if not counters:
+        return st
     # Work counters (BVH nodes fetched, triangle tests) come from a separate
     # instrumented pass so that they do not slow the timed kernels down.
     r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
@@ -213,23 +217,31 @@ def main():
     r.close()
 
     prof = kernel_profile(pt, args, args.scene, device, rank, world)
+    # the same kernels one at a time (one stream): what a launch takes when it has the GPU to itself
+    prof_alone = kernel_profile(pt, args, args.scene, device, rank, world, batch_streams=1, counters=False)
     out = None
     if rank == 0:
         seg, paths = prof["segments"], prof["paths"]
-        shaded = prof["hits_shaded"]  # surface hits handed to the shade kernel
-        extend_bytes = EXTEND_READ_PER_RAY * seg + EXTEND_WRITE_PER_HIT * shaded
-        shade_bytes = SHADE_READ_PER_HIT * shaded + SHADE_WRITE_PER_SURVIVOR * shaded
-        kernels = {
-            "extend": {"ms_total": prof["ms_extend"], "launches": prof["launches_extend"], "algorithmic_bytes": extend_bytes},
-            "shade": {"ms_total": prof["ms_shade"], "launches": prof["launches_shade"], "algorithmic_bytes": shade_bytes},
-            "raygen": {"ms_total": prof["ms_raygen"], "launches": prof["launches_raygen"],
-                       "algorithmic_bytes": RAYGEN_BYTES_PER_PATH * paths},
-            "accumulate": {"ms_total": prof["ms_accumulate"], "launches": prof["launches_accumulate"],
-                           "algorithmic_bytes": 16 * paths + 32 * n_pixels * prof["launches_accumulate"]},
-        }
-        for k in kernels.values():
-            k["avg_launch_ms"] = k["ms_total"] / max(1, k["launches"])
-            k["achieved_GBs"] = k["algorithmic_bytes"] / max(k["ms_total"], 1e-9) / 1e6
+
+        def kernel_table(p):
+            shaded = p["hits_shaded"]  # surface hits handed to the shade kernel
+            extend_bytes = EXTEND_READ_PER_RAY * p["segments"] + EXTEND_WRITE_PER_HIT * shaded
+            shade_bytes = SHADE_READ_PER_HIT * shaded + SHADE_WRITE_PER_SURVIVOR * shaded
+            table = {
+                "extend": {"ms_total": p["ms_extend"], "launches": p["launches_extend"], "algorithmic_bytes": extend_bytes},
+                "shade": {"ms_total": p["ms_shade"], "launches": p["launches_shade"], "algorithmic_bytes": shade_bytes},
+                "raygen": {"ms_total": p["ms_raygen"], "launches": p["launches_raygen"],
+                           "algorithmic_bytes": RAYGEN_BYTES_PER_PATH * p["paths"]},
+                "accumulate": {"ms_total": p["ms_accumulate"], "launches": p["launches_accumulate"],
+                               "algorithmic_bytes": 16 * p["paths"] + 32 * n_pixels * p["launches_accumulate"]},
+            }
+            for k in table.values():
+                k["avg_launch_ms"] = k["ms_total"] / max(1, k["launches"])
+                k["achieved_GBs"] = k["algorithmic_bytes"] / max(k["ms_total"], 1e-9) / 1e6
+            return table
+
+        kernels = kernel_table(prof)
+        alone = kernel_table(prof_alone)
         dom = max(("extend", "shade"), key=lambda n: kernels[n]["ms_total"])
         achieved = kernels[dom]["achieved_GBs"]
         # counted work for the VALU view: box tests ~ 2 x 17 flops per node, triangle test ~ 85 flops
@@ -257,6 +269,10 @@ def main():
                     "lane_occupancy": occupancy,
                     "avg_launch_ms": kernels[dom]["avg_launch_ms"],
                     "bytes_per_launch": kernels[dom]["algorithmic_bytes"] / max(1, kernels[dom]["launches"]),
+                    # The timed run keeps two batches in flight on two streams, so a launch above shares the GPU
+                    # with the other batch's kernels.  One batch at a time (pt_config.batch_streams = 1):
+                    "alone": {"avg_launch_ms": alone[dom]["avg_launch_ms"], "achieved": alone[dom]["achieved_GBs"],
+                              "frac": alone[dom]["achieved_GBs"] / HBM_PEAK_GBS, "kernels": alone},
                     "valu_view": {"extend_counted_gflop": flops / 1e9,
                                   "extend_tflops": flops / max(prof["ms_extend"], 1e-9) / 1e9,
                                   "peak_tflops": VALU_PEAK_TFLOPS,

@@ -80,6 +80,13 @@ typedef struct {
                                       million triangles.  With 1, pt_create fails on input
                                       that needs the host builder's object-median fall-back
                                       (see pt_last_error).                                  */
+    uint32_t batch_streams;        /* 0 or 2 (default): consecutive batches alternate between two
+                                      sets of path buffers on two HIP streams, so that kernels of
+                                      two batches run side by side (the traversal kernel is bound
+                                      by VALU issue, the others by HBM; +18 % paths/s); the
+                                      accumulate kernels are ordered by events, the image is the
+                                      same.  1: one set, one stream, kernels strictly in sequence
+                                      (half the queue memory; per-kernel timings in isolation).  */
 } pt_config;
 
 typedef struct {

@@ -68,6 +68,7 @@ class Config(C.Structure):
         ("profile", C.c_uint32),
         ("emulate_rgba8", C.c_uint32),
         ("bvh_builder", C.c_uint32),
+        ("batch_streams", C.c_uint32),
     ]
 
 
@@ -371,7 +372,7 @@ class Renderer:
     def __init__(self, scene: Scene, camera: Optional[Camera] = None, *, max_depth: int = 10,
                  fov_y_degrees: float = 19.5, device: int = -1, use_bvh: bool = True,
                  iterations_per_batch: int = 0, profile: int = 0, emulate_rgba8: bool = False,
-                 bvh_builder: str = "auto"):
+                 bvh_builder: str = "auto", batch_streams: int = 2):
         self.scene = scene
         self.camera = camera if camera is not None else Camera()
         w, h = self.camera.resolution
@@ -388,6 +389,7 @@ class Renderer:
         if bvh_builder not in ("host", "device", "auto"):
             raise ValueError("bvh_builder is 'host', 'device' or 'auto'")
         cfg.bvh_builder = {"host": 0, "device": 1, "auto": 2}[bvh_builder]
+        cfg.batch_streams = int(batch_streams)  # 2: batches alternate between two streams; 1: strictly in sequence
         self.config = cfg
         self._h = _vp()
         d = scene.desc()

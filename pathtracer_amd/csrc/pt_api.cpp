@@ -125,6 +125,23 @@ struct pt_renderer {
     uint64_t scene_hash = 0;                  // FNV-1a over the scene arrays (checkpoint compatibility)
     uint8_t *d_rgba8 = nullptr;               // emulated 8-bit accumulation texture (cfg.emulate_rgba8)
     uint32_t bvh_builder = 0;                 // the builder that made the tree (0 host, 1 device)
+
+    // Second set of batch buffers with a stream of its own.  Consecutive batches alternate between the
+    // two sets, so that the kernels of two batches are in flight together: the traversal kernel is bound by
+    // VALU issue and the shade / raygen / accumulate kernels by HBM, and a kernel's thinning tail is filled
+    // by the other batch's work.  Only the accumulate kernels are ordered against each other (events), in
+    // batch order, so the image is the one a single stream produces.
+    bool two_lanes = false;
+    hipStream_t stream2 = nullptr;
+    pt::PathQueue q2[2] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+    float4 *d_hits2 = nullptr, *d_samples2 = nullptr;
+    uint32_t *d_counts2 = nullptr;
+    uint32_t sample_tag2 = 0;
+    hipEvent_t ev_accum[2] = {nullptr, nullptr};  // recorded after a set's accumulate kernel
+    bool ev_accum_set[2] = {false, false};
+    hipEvent_t ev_ops = nullptr;                  // recorded on `stream` after work the second stream must wait for
+    bool ops_pending = false;
+    uint32_t next_lane = 0;
     bool scene_in_lds = true;                 // extend keeps nodes (and triangles) in LDS when they fit
     unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics [12] hits shaded [13] shade batches
 
@@ -149,8 +166,39 @@ struct pt_renderer {
 
 namespace {
 
+// Waits for everything the renderer has enqueued, on both of its streams.
+hipError_t sync_streams(pt_renderer *r)
+{
+    hipError_t e = hipSuccess;
+    if (r->stream2) e = hipStreamSynchronize(r->stream2);
+    const hipError_t e1 = r->stream ? hipStreamSynchronize(r->stream) : hipSuccess;
+    return e != hipSuccess ? e : e1;
+}
+
+// Work just enqueued on the main stream touches what the second stream's next batch uses (the sum buffer,
+// the counters): that batch will wait for it.
+void mark_main_stream_work(pt_renderer *r)
+{
+    if (!r->two_lanes) return;
+    (void)hipEventRecord(r->ev_ops, r->stream);
+    r->ops_pending = true;
+}
+
 void free_paths(pt_renderer *r)
 {
+    for (int k = 0; k < 2; ++k) {
+        if (r->q2[k].p0) (void)hipFree(r->q2[k].p0);
+        if (r->q2[k].p1) (void)hipFree(r->q2[k].p1);
+        if (r->q2[k].p2) (void)hipFree(r->q2[k].p2);
+        if (r->q2[k].lt) (void)hipFree(r->q2[k].lt);
+        r->q2[k] = pt::PathQueue{nullptr, nullptr, nullptr, nullptr};
+    }
+    if (r->d_hits2) (void)hipFree(r->d_hits2);
+    if (r->d_samples2) (void)hipFree(r->d_samples2);
+    if (r->d_counts2) (void)hipFree(r->d_counts2);
+    r->d_hits2 = r->d_samples2 = nullptr;
+    r->d_counts2 = nullptr;
+    r->ev_accum_set[0] = r->ev_accum_set[1] = false;
     for (int k = 0; k < 2; ++k) {
         if (r->q[k].p0) (void)hipFree(r->q[k].p0);
         if (r->q[k].p1) (void)hipFree(r->q[k].p1);
@@ -225,6 +273,19 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
     PT_HIP(hipMalloc(&r->d_samples, r->capacity * sizeof(float4)));
     PT_HIP(hipMemsetAsync(r->d_samples, 0, r->capacity * sizeof(float4), r->stream));  // tag 0 = never written
     r->sample_tag = 0;
+    if (r->two_lanes) {
+        for (int b = 0; b < 2; ++b) {
+            PT_HIP(hipMalloc(&r->q2[b].p0, r->capacity * sizeof(float4)));
+            PT_HIP(hipMalloc(&r->q2[b].p1, r->capacity * sizeof(float4)));
+            PT_HIP(hipMalloc(&r->q2[b].p2, r->capacity * sizeof(float4)));
+            PT_HIP(hipMalloc(&r->q2[b].lt, r->capacity * sizeof(float)));
+        }
+        PT_HIP(hipMalloc(&r->d_counts2, static_cast<size_t>(2 * r->cfg.max_depth + 1) * r->region_pitch * sizeof(uint32_t)));
+        PT_HIP(hipMalloc(&r->d_hits2, static_cast<size_t>(r->region_pitch) * r->region_size * sizeof(float4)));
+        PT_HIP(hipMalloc(&r->d_samples2, r->capacity * sizeof(float4)));
+        PT_HIP(hipMemsetAsync(r->d_samples2, 0, r->capacity * sizeof(float4), r->stream2));
+        r->sample_tag2 = 0;
+    }
     PT_HIP(hipMalloc(&r->d_sum, n_pixels * sizeof(float4)));
     if (r->cfg.emulate_rgba8) PT_HIP(hipMalloc(&r->d_rgba8, n_pixels * 4));
     PT_HIP(hipMemsetAsync(r->d_sum, 0, n_pixels * sizeof(float4), r->stream));
@@ -253,8 +314,9 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
 // regions (k * stride) mod n_regions, k = w, w + n_waves, ...; a stride near
 // the golden ratio of n_regions, coprime to it, scatters neighbouring image
 // areas over different waves.
-pt::Regions regions_for(const pt_renderer *r, size_t n_items, uint32_t row_in, int row_out)
+pt::Regions regions_for(const pt_renderer *r, size_t n_items, uint32_t row_in, int row_out, uint32_t *counts = nullptr)
 {
+    if (!counts) counts = r->d_counts;
     pt::Regions g;
     g.size = r->region_size;
     g.n_regions = static_cast<uint32_t>(std::max<size_t>(1, (n_items + g.size - 1) / g.size));
@@ -262,8 +324,8 @@ pt::Regions regions_for(const pt_renderer *r, size_t n_items, uint32_t row_in, i
     while (gcd_u32(stride, g.n_regions) != 1u) stride += 2u;
     g.stride = g.n_regions == 1 ? 1u : stride % g.n_regions;
     if (g.stride == 0) g.stride = 1;
-    g.counts_in = r->d_counts + static_cast<size_t>(row_in) * r->region_pitch;
-    g.counts_out = row_out < 0 ? nullptr : r->d_counts + static_cast<size_t>(row_out) * r->region_pitch;
+    g.counts_in = counts + static_cast<size_t>(row_in) * r->region_pitch;
+    g.counts_out = row_out < 0 ? nullptr : counts + static_cast<size_t>(row_out) * r->region_pitch;
     return g;
 }
 
@@ -278,9 +340,11 @@ pt::LaunchShape shape_for(const pt_renderer *r, size_t work_items)
 
 int reset_accumulation(pt_renderer *r)
 {
+    if (r->stream2) PT_HIP(hipStreamSynchronize(r->stream2));  // its last accumulate still adds to the sum
     PT_HIP(hipMemsetAsync(r->d_sum, 0, static_cast<size_t>(r->width) * r->height * sizeof(float4), r->stream));
     PT_HIP(hipMemsetAsync(r->d_counters, 0, 14 * sizeof(unsigned long long), r->stream));
     if (r->d_rgba8) PT_HIP(hipMemsetAsync(r->d_rgba8, 0, static_cast<size_t>(r->width) * r->height * 4, r->stream));
+    mark_main_stream_work(r);
     r->local_iterations = 0;
     r->paths = 0;
     for (int k = 0; k < 4; ++k) {
@@ -294,18 +358,19 @@ int reset_accumulation(pt_renderer *r)
 struct Timed {
     pt_renderer *r;
     int slot;
+    hipStream_t stream;
     hipEvent_t a = nullptr, b = nullptr;
-    Timed(pt_renderer *r_, int slot_) : r(r_), slot(slot_)
+    Timed(pt_renderer *r_, int slot_, hipStream_t stream_) : r(r_), slot(slot_), stream(stream_)
     {
         if (!(r->cfg.profile & 1u)) return;
         (void)hipEventCreate(&a);
         (void)hipEventCreate(&b);
-        (void)hipEventRecord(a, r->stream);
+        (void)hipEventRecord(a, stream);
     }
     ~Timed()
     {
         if (!(r->cfg.profile & 1u)) return;
-        (void)hipEventRecord(b, r->stream);
+        (void)hipEventRecord(b, stream);
         r->timed.push_back(pt_renderer::TimedLaunch{a, b, slot});
     }
 };
@@ -334,39 +399,58 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     pt::TraversalCounters tc{nullptr, nullptr, nullptr};
     if (r->cfg.profile & 2u) tc = pt::TraversalCounters{r->d_counters + 2, r->d_counters + 3, r->d_counters + 4};
     const pt::LaunchShape g = shape_for(r, n_paths);
-    if (++r->sample_tag == 0u) r->sample_tag = 1u;  // 0 is the tag of the cleared buffer
+    // the set of batch buffers this batch runs in, and its stream
+    const uint32_t lane = r->two_lanes ? (r->next_lane++ & 1u) : 0u;
+    hipStream_t st = lane ? r->stream2 : r->stream;
+    pt::PathQueue *q = lane ? r->q2 : r->q;
+    float4 *d_hits = lane ? r->d_hits2 : r->d_hits, *d_samples = lane ? r->d_samples2 : r->d_samples;
+    uint32_t *d_counts = lane ? r->d_counts2 : r->d_counts;
+    uint32_t &tag = lane ? r->sample_tag2 : r->sample_tag;
+    if (lane && r->ops_pending) {
+        PT_HIP(hipStreamWaitEvent(st, r->ev_ops, 0));
+        r->ops_pending = false;
+    }
+    if (++tag == 0u) tag = 1u;  // 0 is the tag of the cleared buffer
     {
-        Timed t(r, 0);
-        pt::launch_raygen(r->stream, g, r->view, r->cam, it_first, r->world, kb, r->q[0], r->d_counts, r->region_size);
+        Timed t(r, 0, st);
+        pt::launch_raygen(st, g, r->view, r->cam, it_first, r->world, kb, q[0], d_counts, r->region_size);
     }
     for (uint32_t b = 0; b < depth; ++b) {
-        const pt::PathQueue &in = r->q[b & 1], &out = r->q[(b + 1) & 1];
+        const pt::PathQueue &in = q[b & 1], &out = q[(b + 1) & 1];
         // The last surface hit needs no new direction -- except that the reference still evaluates the BSDF
         // there, and a NaN it produces becomes the path's sample: the 8-bit emulation runs that last shade too.
         const bool last = (b + 1 == depth) && !r->cfg.emulate_rgba8;
         const int hit_row = static_cast<int>(depth + 1 + b);
         {
-            Timed t(r, 1);
-            pt::ExtendOutput eo{true, r->d_hits, r->d_samples, true, last, false, r->sample_tag,
-                                b == 0 ? &r->cam : nullptr};
-            pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, hit_row), in,
+            Timed t(r, 1, st);
+            pt::ExtendOutput eo{true, d_hits, d_samples, true, last, false, tag, b == 0 ? &r->cam : nullptr};
+            pt::launch_extend(st, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, hit_row, d_counts), in,
                               eo, tc, r->n_nodes, r->scene_in_lds);
         }
         if (!last) {
-            Timed t(r, 2);
-            pt::launch_shade(r->stream, g, r->view, regions_for(r, n_paths, static_cast<uint32_t>(hit_row), static_cast<int>(b) + 1), in,
-                             r->d_hits, out, r->d_samples, r->sample_tag, b == 0 ? &r->cam : nullptr);
+            Timed t(r, 2, st);
+            pt::launch_shade(st, g, r->view,
+                             regions_for(r, n_paths, static_cast<uint32_t>(hit_row), static_cast<int>(b) + 1, d_counts), in, d_hits,
+                             out, d_samples, tag, b == 0 ? &r->cam : nullptr);
         }
     }
     {
-        Timed t(r, 3);
-        pt::launch_accumulate(r->stream, shape_for(r, n_pixels), r->d_samples, r->d_sum, static_cast<uint32_t>(n_pixels), kb,
-                              r->d_counts, depth, regions_for(r, n_paths, 0, -1).n_regions, r->region_pitch, r->d_counters, r->d_counters + 12,
-                              r->d_counters + 1, r->d_rgba8, it_first, r->world, r->sample_tag);
+        // sum += samples in batch order: wait for the other set's accumulate, which belongs to the batch before
+        if (r->ev_accum_set[lane ^ 1u]) PT_HIP(hipStreamWaitEvent(st, r->ev_accum[lane ^ 1u], 0));
+        {
+            Timed t(r, 3, st);
+            pt::launch_accumulate(st, shape_for(r, n_pixels), d_samples, r->d_sum, static_cast<uint32_t>(n_pixels), kb, d_counts,
+                                  depth, regions_for(r, n_paths, 0, -1, d_counts).n_regions, r->region_pitch, r->d_counters,
+                                  r->d_counters + 12, r->d_counters + 1, r->d_rgba8, it_first, r->world, tag);
+        }
+        if (r->two_lanes) {
+            PT_HIP(hipEventRecord(r->ev_accum[lane], st));
+            r->ev_accum_set[lane] = true;
+        }
     }
     PT_HIP(hipGetLastError());
-    if (r->cfg.profile & 1u) {
-        PT_HIP(hipStreamSynchronize(r->stream));
+    if ((r->cfg.profile & 1u) && r->timed.size() > 8192) {
+        PT_HIP(sync_streams(r));
         drain_events(r);
     }
     r->local_iterations += kb;
@@ -788,6 +872,7 @@ void pt_config_default(pt_config *cfg)
     cfg->profile = 0;
     cfg->emulate_rgba8 = 0;
     cfg->bvh_builder = 2;
+    cfg->batch_streams = 2;
 }
 
 int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer **out)
@@ -834,6 +919,13 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     };
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipStreamCreate failed"));
+    r->two_lanes = cfg.batch_streams != 1u && std::getenv("PT_ONE_LANE") == nullptr;  // (environment: experiments only)
+    if (r->two_lanes) {
+        bool ok = hipStreamCreateWithFlags(&r->stream2, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k) ok = hipEventCreateWithFlags(&r->ev_accum[k], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&r->ev_ops, hipEventDisableTiming) == hipSuccess;
+        if (!ok) return bail(fail(PT_ERR_DEVICE, "hipStreamCreate / hipEventCreate failed"));
+    }
     if ((rc = upload_scene(r, scene)) != PT_OK) return bail(rc);
     if (hipMalloc(&r->d_counters, 14 * sizeof(unsigned long long)) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipMalloc failed"));
@@ -850,7 +942,7 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
         r->cam.right[k] = def.m_right[k];
     }
     if ((rc = reset_accumulation(r)) != PT_OK) return bail(rc);
-    if (hipStreamSynchronize(r->stream) != hipSuccess) return bail(fail(PT_ERR_DEVICE, "initial synchronise failed"));
+    if (sync_streams(r) != hipSuccess) return bail(fail(PT_ERR_DEVICE, "initial synchronise failed"));
     *out = r;
     return PT_OK;
 }
@@ -859,9 +951,12 @@ void pt_destroy(pt_renderer *r)
 {
     if (!r) return;
     (void)hipSetDevice(r->device);
-    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    (void)sync_streams(r);
     drain_events(r);
     free_paths(r);
+    for (hipEvent_t e : {r->ev_accum[0], r->ev_accum[1], r->ev_ops})
+        if (e) (void)hipEventDestroy(e);
+    if (r->stream2) (void)hipStreamDestroy(r->stream2);
     void *bufs[] = {r->d_nodes, r->d_tris, r->d_shade, r->d_materials, r->d_lights, r->d_counters};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -886,7 +981,7 @@ int pt_resize(pt_renderer *r, uint32_t width, uint32_t height)
 {
     PT_REQUIRE(r && width >= 1 && height >= 1, "pt_resize: bad argument");
     PT_HIP(hipSetDevice(r->device));
-    PT_HIP(hipStreamSynchronize(r->stream));
+    PT_HIP(sync_streams(r));
     int rc = alloc_paths(r, width, height);
     if (rc != PT_OK) return rc;
     r->cfg.width = width;
@@ -1005,7 +1100,7 @@ int pt_load_state(pt_renderer *r, const char *path)
     int rc = reset_accumulation(r);
     if (rc != PT_OK) return rc;
     PT_HIP(hipMemcpyAsync(r->d_sum, sum.data(), n * sizeof(float), hipMemcpyHostToDevice, r->stream));
-    PT_HIP(hipStreamSynchronize(r->stream));
+    PT_HIP(sync_streams(r));
     r->local_iterations = h.local_iterations;
     r->paths = h.paths;
     return PT_OK;
@@ -1015,7 +1110,7 @@ int pt_synchronize(pt_renderer *r)
 {
     PT_REQUIRE(r, "pt_synchronize: null argument");
     PT_HIP(hipSetDevice(r->device));
-    PT_HIP(hipStreamSynchronize(r->stream));
+    PT_HIP(sync_streams(r));
     return PT_OK;
 }
 
@@ -1023,9 +1118,10 @@ int pt_read_sum(pt_renderer *r, float *rgba)
 {
     PT_REQUIRE(r && rgba, "pt_read_sum: null argument");
     PT_HIP(hipSetDevice(r->device));
+    PT_HIP(sync_streams(r));  // batches of both streams add to the sum
     PT_HIP(hipMemcpyAsync(rgba, r->d_sum, static_cast<size_t>(r->width) * r->height * sizeof(float4), hipMemcpyDeviceToHost,
                           r->stream));
-    PT_HIP(hipStreamSynchronize(r->stream));
+    PT_HIP(sync_streams(r));
     return PT_OK;
 }
 
@@ -1034,8 +1130,9 @@ int pt_read_rgba8(pt_renderer *r, uint8_t *rgba)
     PT_REQUIRE(r && rgba, "pt_read_rgba8: null argument");
     if (!r->d_rgba8) return fail(PT_ERR_STATE, "pt_read_rgba8: the renderer was created without emulate_rgba8");
     PT_HIP(hipSetDevice(r->device));
+    PT_HIP(sync_streams(r));
     PT_HIP(hipMemcpyAsync(rgba, r->d_rgba8, static_cast<size_t>(r->width) * r->height * 4, hipMemcpyDeviceToHost, r->stream));
-    PT_HIP(hipStreamSynchronize(r->stream));
+    PT_HIP(sync_streams(r));
     return PT_OK;
 }
 
@@ -1060,10 +1157,11 @@ int pt_read_tonemapped(pt_renderer *r, uint8_t *rgb)
     PT_HIP(hipSetDevice(r->device));
     const size_t n = static_cast<size_t>(r->width) * r->height;
     uint8_t *d = nullptr;
+    PT_HIP(sync_streams(r));
     PT_HIP(hipMalloc(&d, 3 * n));
     pt::launch_tonemap(r->stream, shape_for(r, n), r->d_sum, d, r->width, r->height);
     hipError_t e = hipMemcpyAsync(rgb, d, 3 * n, hipMemcpyDeviceToHost, r->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    if (e == hipSuccess) e = sync_streams(r);
     (void)hipFree(d);
     PT_HIP(e);
     return PT_OK;
@@ -1073,7 +1171,7 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
 {
     PT_REQUIRE(r && (ids || t || dirs), "pt_read_hit_ids: null argument");
     PT_HIP(hipSetDevice(r->device));
-    PT_HIP(hipStreamSynchronize(r->stream));
+    PT_HIP(sync_streams(r));
     const size_t n = static_cast<size_t>(r->width) * r->height;
     int32_t *d_ids = nullptr;
     float *d_t = nullptr, *d_dirs = nullptr;
@@ -1105,7 +1203,7 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
     if (ids) PT_TRY(hipMemcpyAsync(ids, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
     if (t) PT_TRY(hipMemcpyAsync(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
     if (dirs) PT_TRY(hipMemcpyAsync(dirs, d_dirs, 3 * n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
-    PT_TRY(hipStreamSynchronize(r->stream));
+    PT_TRY(sync_streams(r));
     cleanup();
     return PT_OK;
 }
@@ -1114,7 +1212,7 @@ int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float 
 {
     PT_REQUIRE(r && (n == 0 || (origins && dirs)), "pt_trace_rays: null argument");
     PT_HIP(hipSetDevice(r->device));
-    PT_HIP(hipStreamSynchronize(r->stream));
+    PT_HIP(sync_streams(r));
     if (n == 0) return PT_OK;
     const size_t chunk_max = r->capacity;
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
@@ -1145,7 +1243,7 @@ int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float 
         PT_TRY(hipGetLastError());
         if (t) PT_TRY(hipMemcpyAsync(t + off, d_t, c * sizeof(float), hipMemcpyDeviceToHost, r->stream));
         if (ids) PT_TRY(hipMemcpyAsync(ids + off, d_ids, c * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
-        PT_TRY(hipStreamSynchronize(r->stream));
+        PT_TRY(sync_streams(r));
     }
     cleanup();
     return PT_OK;
@@ -1185,7 +1283,7 @@ int pt_sample_surface(pt_renderer *r, uint64_t n, const float *materials, const 
     PT_TRY(hipMemcpyAsync(f_out, d_f, 3 * n * 4, hipMemcpyDeviceToHost, r->stream));
     PT_TRY(hipMemcpyAsync(flags_out, d_flags, n * 4, hipMemcpyDeviceToHost, r->stream));
     PT_TRY(hipMemcpyAsync(seeds_out, d_seed_out, 2 * n * 4, hipMemcpyDeviceToHost, r->stream));
-    PT_TRY(hipStreamSynchronize(r->stream));
+    PT_TRY(sync_streams(r));
     cleanup();
     return PT_OK;
 }
@@ -1201,6 +1299,8 @@ int pt_set_exact_readbacks(pt_renderer *r, uint32_t enabled)
 int pt_sum_device_ptr(pt_renderer *r, void **dev_ptr)
 {
     PT_REQUIRE(r && dev_ptr, "pt_sum_device_ptr: null argument");
+    PT_HIP(hipSetDevice(r->device));
+    PT_HIP(sync_streams(r));  // the caller reads the buffer on a stream of its own
     *dev_ptr = r->d_sum;
     return PT_OK;
 }
@@ -1208,7 +1308,7 @@ int pt_sum_device_ptr(pt_renderer *r, void **dev_ptr)
 int pt_read_bvh(pt_renderer *r, float *nodes_host, float *triangles_host)
 {
     PT_REQUIRE(r, "pt_read_bvh: null argument");
-    PT_HIP(hipStreamSynchronize(r->stream));
+    PT_HIP(sync_streams(r));
     if (nodes_host && r->n_nodes) PT_HIP(hipMemcpy(nodes_host, r->d_nodes, static_cast<size_t>(r->n_nodes) * 64, hipMemcpyDeviceToHost));
     if (triangles_host && r->view.n_triangles)
         PT_HIP(hipMemcpy(triangles_host, r->d_tris, static_cast<size_t>(r->view.n_triangles) * 64, hipMemcpyDeviceToHost));
@@ -1303,7 +1403,7 @@ int pt_get_stats(pt_renderer *r, pt_stats *s)
 {
     PT_REQUIRE(r && s, "pt_get_stats: null argument");
     PT_HIP(hipSetDevice(r->device));
-    PT_HIP(hipStreamSynchronize(r->stream));
+    PT_HIP(sync_streams(r));
     drain_events(r);
     unsigned long long c[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     PT_HIP(hipMemcpy(c, r->d_counters, sizeof(c), hipMemcpyDeviceToHost));

@@ -28,6 +28,33 @@ def test_progressive_accumulation_is_independent_of_call_and_batch_split(pt):
     assert np.all(sums[0][..., 3] == 12)
 
 
+def test_two_streams_render_the_image_of_one(pt):
+    # batches alternate between two sets of buffers on two streams; the accumulate kernels are ordered,
+    # so the sum is the same bit for bit as with every kernel in sequence on one stream
+    out = []
+    for streams, calls in [(1, [5] * 6), (2, [5] * 6), (2, [30]), (2, [1] * 30)]:
+        r = _renderer(pt, "Box_Transmission", 160, 96, max_depth=7, iterations_per_batch=5, batch_streams=streams)
+        for c in calls:
+            r.draw(c)
+        out.append((r.read_sum(), r.stats()))
+        r.close()
+    for s, st in out[1:]:
+        assert np.array_equal(s, out[0][0])
+        assert st["segments"] == out[0][1]["segments"] and st["hits_shaded"] == out[0][1]["hits_shaded"]
+    # a reset or a camera change between batches of different streams is ordered against both
+    r = _renderer(pt, "Box", 128, 64, max_depth=5, iterations_per_batch=2)
+    r.draw(6)
+    r.reset()
+    r.draw(3)
+    a = r.read_sum()
+    r.close()
+    r = _renderer(pt, "Box", 128, 64, max_depth=5, iterations_per_batch=2, batch_streams=1)
+    r.draw(3)
+    b = r.read_sum()
+    r.close()
+    assert np.array_equal(a, b) and np.all(a[..., 3] == 3)
+
+
 def test_deterministic_across_runs(pt):
     a = []
     for _ in range(2):
