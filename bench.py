@@ -53,6 +53,9 @@ def parse_args():
     p.add_argument("--lattice", type=int, default=0,
                    help="instance the scene's shapes (all but its 10 room triangles) on an N^3 lattice")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-alone", action="store_true",
+                   help="skip the pass that times every kernel alone on one stream (profiling runs: every "
+                        "launch of the run is then of the overlapped kind)")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary Veggie.obj measurement")
     return p.parse_args()
 
@@ -218,7 +221,8 @@ def main():
 
     prof = kernel_profile(pt, args, args.scene, device, rank, world)
     # the same kernels one at a time (one stream): what a launch takes when it has the GPU to itself
-    prof_alone = kernel_profile(pt, args, args.scene, device, rank, world, batch_streams=1, counters=False)
+    prof_alone = None if args.no_alone else kernel_profile(pt, args, args.scene, device, rank, world, batch_streams=1,
+                                                            counters=False)
     out = None
     if rank == 0:
         seg, paths = prof["segments"], prof["paths"]
@@ -241,7 +245,7 @@ def main():
             return table
 
         kernels = kernel_table(prof)
-        alone = kernel_table(prof_alone)
+        alone = kernel_table(prof_alone) if prof_alone else None
         dom = max(("extend", "shade"), key=lambda n: kernels[n]["ms_total"])
         achieved = kernels[dom]["achieved_GBs"]
         # counted work for the VALU view: box tests ~ 2 x 17 flops per node, triangle test ~ 85 flops
@@ -272,7 +276,7 @@ def main():
                     # The timed run keeps two batches in flight on two streams, so a launch above shares the GPU
                     # with the other batch's kernels.  One batch at a time (pt_config.batch_streams = 1):
                     "alone": {"avg_launch_ms": alone[dom]["avg_launch_ms"], "achieved": alone[dom]["achieved_GBs"],
-                              "frac": alone[dom]["achieved_GBs"] / HBM_PEAK_GBS, "kernels": alone},
+                              "frac": alone[dom]["achieved_GBs"] / HBM_PEAK_GBS, "kernels": alone} if alone else None,
                     "valu_view": {"extend_counted_gflop": flops / 1e9,
                                   "extend_tflops": flops / max(prof["ms_extend"], 1e-9) / 1e9,
                                   "peak_tflops": VALU_PEAK_TFLOPS,

@@ -1221,10 +1221,15 @@ namespace {
 // size), so no block waits for another to retire, and never more waves than
 // there are regions to hand out.
 template <typename K>
-uint32_t resident_grid(K kernel, size_t lds_bytes, LaunchShape g, int block = kBlock)
+uint32_t resident_grid(K kernel, size_t lds_bytes, LaunchShape g, int block = kBlock, const char *cap_env = nullptr)
 {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (cap_env) {  // tuning experiments only: fewer blocks per CU than fit
+        const char *e = std::getenv(cap_env);
+        const int cap = e ? std::atoi(e) : 0;
+        if (cap >= 1 && cap < per_cu) per_cu = cap;
+    }
     const uint32_t resident = g.n_cus * static_cast<uint32_t>(per_cu);
     const uint32_t needed = (g.wave_items + (block / 64) - 1) / (block / 64);
     if (std::getenv("PT_EVEN_GRID")) {  // tuning experiments only
@@ -1339,7 +1344,7 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_bvh<C, E, L, R, T>),                  \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));     \
         hipLaunchKernelGGL((k_extend_bvh<C, E, L, R, T>),                                                         \
-                           dim3(resident_grid(k_extend_bvh<C, E, L, R, T>, lds_bytes, g, kExtBlock)),               \
+                           dim3(resident_grid(k_extend_bvh<C, E, L, R, T>, lds_bytes, g, kExtBlock, "PT_EXT_PER_CU")), \
                            dim3(kExtBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples,            \
                            last, tc, n_nodes, refill_at, stack_entries, n_lds_nodes, out.sample_tag,   \
                            primary_cam, primary);            \
@@ -1375,7 +1380,7 @@ void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions 
                   const float4 *hit_list, PathQueue out, float4 *samples, uint32_t sample_tag,
                   const DeviceCamera *primary_of)
 {
-    hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g)), dim3(kBlock), 0, s, scene, regions, in, hit_list, out,
+    hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g, kBlock, "PT_SHADE_PER_CU")), dim3(kBlock), 0, s, scene, regions, in, hit_list, out,
                        samples, sample_tag, primary_of ? *primary_of : DeviceCamera{}, primary_of ? 1u : 0u);
 }
 

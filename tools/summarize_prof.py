@@ -19,13 +19,24 @@ def short(name):
     return m.group(1) if m else name[:40]
 
 
-print("== kernel trace (rocprofv3 --kernel-trace --stats) ==")
-for f in glob.glob(os.path.join(out, "kt", "**", "*kernel_stats.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
-        print(f"{short(row['Name']):34s} calls {int(row['Calls']):5d}  total {float(row['TotalDurationNs'])/1e6:9.3f} ms  "
-              f"avg {float(row['AverageNs'])/1e3:9.2f} us  {float(row['Percentage']):6.2f} %")
-        machine.setdefault(short(row['Name']), {})["avg_launch_us"] = float(row['AverageNs']) / 1e3
-        machine[short(row['Name'])]["launches"] = int(row['Calls'])
+# kt: the run as benchmarked (two batches in flight, launches of the two streams overlap);
+# kt_alone: the same run with one batch at a time, every kernel alone on the GPU -- the
+# duration the counters of the PMC passes (which serialise kernels) belong to.
+for sub, title, key in (("kt", "kernel trace (rocprofv3 --kernel-trace --stats), two batches in flight", "avg_launch_us_overlapped"),
+                        ("kt_alone", "kernel trace, one batch at a time (PT_ONE_LANE=1)", "avg_launch_us")):
+    files = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if not files:
+        continue
+    print(f"== {title} ==")
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            print(f"{short(row['Name']):34s} calls {int(row['Calls']):5d}  total {float(row['TotalDurationNs'])/1e6:9.3f} ms  "
+                  f"avg {float(row['AverageNs'])/1e3:9.2f} us  {float(row['Percentage']):6.2f} %")
+            machine.setdefault(short(row['Name']), {})[key] = float(row['AverageNs']) / 1e3
+            machine[short(row['Name'])]["launches"] = int(row['Calls'])
+    print()
+for m in machine.values():  # a profile without the second trace: the only duration there is
+    m.setdefault("avg_launch_us", m.get("avg_launch_us_overlapped", 0.0))
 
 for p in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(p):
