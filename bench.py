@@ -10,9 +10,14 @@ iterations g, g+G, ...).  The per-GPU radiance sums are combined by one
 reduce (RCCL when G > 1) at the end of the timed region.  Rank 0 prints ONE
 JSON line; `value` is whole-job Mpaths/s.
 
+The renderer keeps two batches in flight (two sets of path buffers, two HIP
+streams), so the launches of consecutive steps overlap on the GPU.
+
 Outside the timed region the same command also
   * checks the primary hit-ID buffer against the reference's (llvmpipe fixture),
-  * re-runs the workload with per-kernel HIP-event timing for the roofline,
+  * re-runs the workload with every launch bracketed by HIP events on the stream it
+    is launched on, once as timed (`roofline`: launches overlap) and once with one
+    batch at a time (`roofline.alone`: every kernel alone on the GPU),
   * times the CPU oracle on a bounded sample of the same workload (rank 0).
 """
 import argparse
