@@ -7,6 +7,7 @@
 #include <cstring>
 #include <limits>
 #include <thread>
+#include <utility>
 
 namespace pt {
 
@@ -18,7 +19,7 @@ const uint32_t kLeafMax = [] {
     const int v = e ? std::atoi(e) : 4;
     return static_cast<uint32_t>(v < 1 ? 1 : (v > 7 ? 7 : v));
 }();
-constexpr int kBins = 16;
+constexpr int kMaxBins = 64;
 // Cost of one inner-node step in units of one triangle test.  (PT_BVH_CT: tuning experiments only.)
 const double kTraversalCost = [] {
     const char *e = std::getenv("PT_BVH_CT");
@@ -79,6 +80,7 @@ struct Builder {
     std::vector<Prim> prims;
     std::vector<TmpNode> tmp;
     bool median_only = false;
+    int kBins = 16;  // centroid bins per axis
 
     // Builds the subtree over prims[begin, end) into `out` and returns its node.
     // With `jobs`, subtrees of at most job_size primitives are not built but
@@ -122,8 +124,8 @@ struct Builder {
             for (int axis = 0; axis < 3; ++axis) {
                 float extent = cbox.hi[axis] - cbox.lo[axis];
                 if (!(extent > 0.f)) continue;
-                Box bin_box[kBins];
-                uint32_t bin_n[kBins];
+                Box bin_box[kMaxBins];
+                uint32_t bin_n[kMaxBins];
                 for (int b = 0; b < kBins; ++b) {
                     bin_box[b].reset();
                     bin_n[b] = 0;
@@ -135,8 +137,8 @@ struct Builder {
                     bin_box[b].grow(prims[i].box);
                     bin_n[b]++;
                 }
-                double right_area[kBins];
-                uint32_t right_n[kBins];
+                double right_area[kMaxBins];
+                uint32_t right_n[kMaxBins];
                 Box acc;
                 acc.reset();
                 uint32_t cnt = 0;
@@ -325,10 +327,11 @@ void renumber_top_breadth_first(std::vector<BvhNode> *nodes, size_t top)
 uint32_t bvh_leaf_max() { return kLeafMax; }
 double bvh_traversal_cost() { return kTraversalCost; }
 
-void build_bvh(const float *vertices, const uint32_t *ids, uint32_t n_triangles, uint32_t max_depth, Bvh *out)
+void build_bvh(const float *vertices, const uint32_t *ids, uint32_t n_triangles, uint32_t max_depth, Bvh *out, int bins)
 {
     *out = Bvh();
     Builder b;
+    b.kBins = bins < 2 ? 2 : (bins > kMaxBins ? kMaxBins : bins);
     b.prims.resize(n_triangles);
     Box scene;
     scene.reset();
@@ -402,6 +405,19 @@ void build_bvh(const float *vertices, const uint32_t *ids, uint32_t n_triangles,
         r.nz = cz * inv_len;
         r.d0 = r.nx * v0[0] + (r.ny * v0[1] + r.nz * v0[2]);
         r.original = t;
+    }
+}
+
+void build_bvh_best_of(const float *vertices, const uint32_t *ids, uint32_t n_triangles, uint32_t max_depth, Bvh *out)
+{
+    static const int many[] = {16, 8, 12, 24, 32, 48, 64}, few[] = {16, 8, 32};
+    const int *bins = n_triangles <= 8192u ? many : few;
+    const int n_bins = n_triangles <= 8192u ? 7 : 3;
+    build_bvh(vertices, ids, n_triangles, max_depth, out, bins[0]);
+    for (int k = 1; k < n_bins; ++k) {
+        Bvh other;
+        build_bvh(vertices, ids, n_triangles, max_depth, &other, bins[k]);
+        if (other.depth <= max_depth && other.sah_cost < out->sah_cost) *out = std::move(other);
     }
 }
 

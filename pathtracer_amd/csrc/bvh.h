@@ -57,8 +57,17 @@ struct Bvh {
 // vertices: xyz triples; tri_vertex_ids: 3 vertex indices per triangle.
 // max_depth bounds the traversal stack the kernel needs: a tree that comes out
 // deeper is rebuilt with object-median splits.
+// bins: centroid bins per axis of the SAH (2..64); the device builder (bvh_device.h) makes
+// the tree of bins = 16.
 void build_bvh(const float *vertices, const uint32_t *tri_vertex_ids, uint32_t n_triangles,
-               uint32_t max_depth, Bvh *out);
+               uint32_t max_depth, Bvh *out, int bins = 16);
+
+// Greedy top-down SAH is sensitive to where the bin boundaries fall (on the bundled scenes the
+// total cost moves by up to 12 % between 8 and 64 bins, in no particular direction), and a
+// small tree takes well under a millisecond to build: this builds the tree with several bin
+// counts (seven up to 8192 triangles, three above) and keeps the one of least SAH cost.
+void build_bvh_best_of(const float *vertices, const uint32_t *tri_vertex_ids, uint32_t n_triangles,
+                       uint32_t max_depth, Bvh *out);
 
 // The two constants of the builder's surface-area heuristic: the largest leaf
 // and the cost of one inner-node step in units of one triangle test.

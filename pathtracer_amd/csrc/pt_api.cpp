@@ -581,7 +581,11 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
         for (int a = 0; a < 3; ++a) bounds_lo[a] = built.bounds_lo[a], bounds_hi[a] = built.bounds_hi[a];
     }
     if (!device_build) {
-        pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
+        // automatic choice: a scene small enough for the host builder gets the best of several bin counts
+        if (automatic && r->cfg.use_bvh && T < kAutoDeviceTriangles)
+            pt::build_bvh_best_of(sc->vertices, ids.data(), T, 64, &bvh);
+        else
+            pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
         if (r->cfg.use_bvh) {
             if (bvh.depth > 64) return fail(PT_ERR_STATE, "BVH deeper than the largest traversal stack");
         } else {
@@ -1329,7 +1333,10 @@ int pt_bvh_inspect(const pt_scene_desc *sc, pt_bvh_info *info)
         }
     const double t0 = now_ms();
     pt::Bvh bvh;
-    pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
+    if (T < (1u << 16))  // as pt_create does with the default (automatic) builder choice
+        pt::build_bvh_best_of(sc->vertices, ids.data(), T, 64, &bvh);
+    else
+        pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
     std::memset(info, 0, sizeof(*info));
     info->build_ms = now_ms() - t0;
     info->n_triangles = T;

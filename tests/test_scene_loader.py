@@ -251,3 +251,9 @@ def test_bvh_build_is_the_same_on_one_thread_and_on_many(pt, monkeypatch):
         for key in ("n_nodes", "n_leaves", "depth", "max_leaf_size", "stack_entries", "n_triangles"):
             assert i[key] == infos[0][key], key
         assert abs(i["sah_cost"] - infos[0]["sah_cost"]) <= 1e-9 * infos[0]["sah_cost"]
+
+
+def test_small_scenes_get_the_best_of_several_sah_binnings(pt):
+    # 16 bins alone give Veggie.obj a tree of SAH cost 13.27; among 8..64 bins the builder finds 11.89
+    info = pt.Scene.from_arrays(**scene_arrays("Veggie")).bvh_info()
+    assert info["sah_cost"] < 12.0 and info["n_triangles"] == 1450 and info["max_leaf_size"] <= 4
