@@ -82,6 +82,12 @@ def timed_run(pt, torch, dist, args, scene_name, rank, world, device, distribute
     for _ in range(args.warmup):
         r.draw(args.spp_per_step)
     r.synchronize()
+    if distributed:
+        # the collective of the timed region once before it (communicator set-up, kernel load)
+        from pathtracer_amd import distributed as ptd
+
+        ptd.reduce_sum_to_root(ptd.sum_buffer_as_tensor(r, f"cuda:{device}"), 0)
+        torch.cuda.synchronize()
     r.reset()
     r.synchronize()
 
