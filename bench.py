@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 A step is one pass of the wavefront integrator over one batch of synthetic
-work: `--spp-per-step` (16) iterations (samples per pixel) of the scene at
+work: `--spp-per-step` (32) iterations (samples per pixel) of the scene at
 1920x1080, max depth 8, on every rank (weak scaling: rank g of G renders
 iterations g, g+G, ...).  The per-GPU radiance sums are combined by one
 reduce (RCCL when G > 1) at the end of the timed region.  Rank 0 prints ONE
@@ -54,7 +54,7 @@ def parse_args():
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--depth", type=int, default=8)
-    p.add_argument("--spp-per-step", type=int, default=16)
+    p.add_argument("--spp-per-step", type=int, default=32)
     p.add_argument("--lattice", type=int, default=0,
                    help="instance the scene's shapes (all but its 10 room triangles) on an N^3 lattice")
     p.add_argument("--no-cpu-baseline", action="store_true")

@@ -236,9 +236,10 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
     const size_t n_pixels = static_cast<size_t>(width) * height;
     uint32_t k = r->cfg.iterations_per_batch;
     if (k == 0) {
-        // Enough paths in flight to keep 256 CUs busy after compaction has
-        // thinned the queue: about 32M slots (4.3 GB of queues), at most 16 samples per pixel.
-        k = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(16, (size_t(32) << 20) / std::max<size_t>(1, n_pixels))));
+        // Enough paths in flight to keep 256 CUs busy after compaction has thinned the queue, and launches
+        // long enough that their ends weigh little: about 64M slots (8.6 GB of queues per set of
+        // buffers), at most 32 samples per pixel.
+        k = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(32, (size_t(64) << 20) / std::max<size_t>(1, n_pixels))));
     }
     // Path slots are 32-bit.
     while (k > 1 && n_pixels * k >= (size_t(1) << 31)) --k;

@@ -21,14 +21,14 @@ import pathtracer_amd as pt  # noqa: E402
 CONFIGS = [
     # name, scene, lattice n, width, height, depth, spp per batch, batches
     ("box_512_d5", "Box", 0, 512, 512, 5, 64, 4),
-    ("box_1080p_d8", "Box", 0, 1920, 1080, 8, 16, 8),
-    ("veggie_1080p_d8", "Veggie", 0, 1920, 1080, 8, 16, 8),
-    ("transmission_1080p_d8", "Box_Transmission", 0, 1920, 1080, 8, 16, 8),
-    ("transmission_sphere_1080p_d8", "Box_TransmissionSphere", 0, 1920, 1080, 8, 16, 8),
-    ("anisotropic_1080p_d8", "Box_Anisotropic", 0, 1920, 1080, 8, 16, 8),
-    ("anisotropic_test_1080p_d8", "AnisotropicTest", 0, 1920, 1080, 8, 16, 8),
-    ("veggie_4k_d8", "Veggie", 0, 3840, 2160, 8, 4, 8),
-    ("veggie_lattice10M_4k_d8", "Veggie", 19, 3840, 2160, 8, 4, 4),
+    ("box_1080p_d8", "Box", 0, 1920, 1080, 8, 32, 6),
+    ("veggie_1080p_d8", "Veggie", 0, 1920, 1080, 8, 32, 6),
+    ("transmission_1080p_d8", "Box_Transmission", 0, 1920, 1080, 8, 32, 6),
+    ("transmission_sphere_1080p_d8", "Box_TransmissionSphere", 0, 1920, 1080, 8, 32, 6),
+    ("anisotropic_1080p_d8", "Box_Anisotropic", 0, 1920, 1080, 8, 32, 6),
+    ("anisotropic_test_1080p_d8", "AnisotropicTest", 0, 1920, 1080, 8, 32, 6),
+    ("veggie_4k_d8", "Veggie", 0, 3840, 2160, 8, 8, 6),
+    ("veggie_lattice10M_4k_d8", "Veggie", 19, 3840, 2160, 8, 8, 4),
 ]
 
 
