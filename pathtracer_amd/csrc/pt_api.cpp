@@ -142,6 +142,7 @@ struct pt_renderer {
     hipEvent_t ev_ops = nullptr;                  // recorded on `stream` after work the second stream must wait for
     bool ops_pending = false;
     uint32_t next_lane = 0;
+    uint32_t lanes_in_use = 1;                    // 2 unless the second set did not fit in memory
     bool scene_in_lds = true;                 // extend keeps nodes (and triangles) in LDS when they fit
     unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics [12] hits shaded [13] shade batches
 
@@ -275,17 +276,40 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
     PT_HIP(hipMemsetAsync(r->d_samples, 0, r->capacity * sizeof(float4), r->stream));  // tag 0 = never written
     r->sample_tag = 0;
     if (r->two_lanes) {
-        for (int b = 0; b < 2; ++b) {
-            PT_HIP(hipMalloc(&r->q2[b].p0, r->capacity * sizeof(float4)));
-            PT_HIP(hipMalloc(&r->q2[b].p1, r->capacity * sizeof(float4)));
-            PT_HIP(hipMalloc(&r->q2[b].p2, r->capacity * sizeof(float4)));
-            PT_HIP(hipMalloc(&r->q2[b].lt, r->capacity * sizeof(float)));
-        }
-        PT_HIP(hipMalloc(&r->d_counts2, static_cast<size_t>(2 * r->cfg.max_depth + 1) * r->region_pitch * sizeof(uint32_t)));
-        PT_HIP(hipMalloc(&r->d_hits2, static_cast<size_t>(r->region_pitch) * r->region_size * sizeof(float4)));
-        PT_HIP(hipMalloc(&r->d_samples2, r->capacity * sizeof(float4)));
-        PT_HIP(hipMemsetAsync(r->d_samples2, 0, r->capacity * sizeof(float4), r->stream2));
+        // the second set of batch buffers; without the memory for it the renderer works with one
+        auto second = [&]() -> hipError_t {
+            hipError_t e = hipSuccess;
+            for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+                e = hipMalloc(&r->q2[b].p0, r->capacity * sizeof(float4));
+                if (e == hipSuccess) e = hipMalloc(&r->q2[b].p1, r->capacity * sizeof(float4));
+                if (e == hipSuccess) e = hipMalloc(&r->q2[b].p2, r->capacity * sizeof(float4));
+                if (e == hipSuccess) e = hipMalloc(&r->q2[b].lt, r->capacity * sizeof(float));
+            }
+            if (e == hipSuccess)
+                e = hipMalloc(&r->d_counts2, static_cast<size_t>(2 * r->cfg.max_depth + 1) * r->region_pitch * sizeof(uint32_t));
+            if (e == hipSuccess) e = hipMalloc(&r->d_hits2, static_cast<size_t>(r->region_pitch) * r->region_size * sizeof(float4));
+            if (e == hipSuccess) e = hipMalloc(&r->d_samples2, r->capacity * sizeof(float4));
+            if (e == hipSuccess) e = hipMemsetAsync(r->d_samples2, 0, r->capacity * sizeof(float4), r->stream2);
+            return e;
+        };
+        const hipError_t e = second();
         r->sample_tag2 = 0;
+        r->lanes_in_use = 2;
+        if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+            (void)hipGetLastError();
+            for (int b = 0; b < 2; ++b) {
+                (void)hipFree(r->q2[b].p0), (void)hipFree(r->q2[b].p1), (void)hipFree(r->q2[b].p2), (void)hipFree(r->q2[b].lt);
+                r->q2[b] = pt::PathQueue{nullptr, nullptr, nullptr, nullptr};
+            }
+            (void)hipFree(r->d_counts2), (void)hipFree(r->d_hits2), (void)hipFree(r->d_samples2);
+            r->d_counts2 = nullptr;
+            r->d_hits2 = r->d_samples2 = nullptr;
+            r->lanes_in_use = 1;
+        } else {
+            PT_HIP(e);
+        }
+    } else {
+        r->lanes_in_use = 1;
     }
     PT_HIP(hipMalloc(&r->d_sum, n_pixels * sizeof(float4)));
     if (r->cfg.emulate_rgba8) PT_HIP(hipMalloc(&r->d_rgba8, n_pixels * 4));
@@ -401,7 +425,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     if (r->cfg.profile & 2u) tc = pt::TraversalCounters{r->d_counters + 2, r->d_counters + 3, r->d_counters + 4};
     const pt::LaunchShape g = shape_for(r, n_paths);
     // the set of batch buffers this batch runs in, and its stream
-    const uint32_t lane = r->two_lanes ? (r->next_lane++ & 1u) : 0u;
+    const uint32_t lane = r->lanes_in_use == 2u ? (r->next_lane++ & 1u) : 0u;
     hipStream_t st = lane ? r->stream2 : r->stream;
     pt::PathQueue *q = lane ? r->q2 : r->q;
     float4 *d_hits = lane ? r->d_hits2 : r->d_hits, *d_samples = lane ? r->d_samples2 : r->d_samples;
