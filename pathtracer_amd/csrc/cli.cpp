@@ -8,6 +8,7 @@
 //             [--light r g b  px py pz  rx ry rz  sx sy sz]  repeatable; replaces the default light
 //             [--no-light]
 //             [--resume state.bin] [--save-state state.bin] [--checkpoint-every n]
+//             [--preview-every n]   rewrite --out after every n samples per pixel (a progressive preview)
 //             [--scan] [--bvh host|device] [--out image.ppm] [--pfm radiance.pfm]
 // --spp is the total: after --resume only the missing samples are rendered.
 #include <algorithm>
@@ -55,7 +56,7 @@ int main(int argc, char **argv)
     pt::Vec3 eye = pt::make3(0.f, 1.5f, 15.f), focus = pt::make3(0.f, -0.25f, 0.f);
     bool scan = false, no_light = false, device_bvh = false;
     std::string resume, save_state;
-    uint32_t checkpoint_every = 0;
+    uint32_t checkpoint_every = 0, preview_every = 0;
     std::vector<pt::Scene::Light> lights;
     struct Move {
         char kind;
@@ -85,6 +86,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--resume")) resume = next(), ++i;
         else if (!std::strcmp(argv[i], "--save-state")) save_state = next(), ++i;
         else if (!std::strcmp(argv[i], "--checkpoint-every")) checkpoint_every = std::atoi(next()), ++i;
+        else if (!std::strcmp(argv[i], "--preview-every")) preview_every = std::atoi(next()), ++i;
         else if (!std::strcmp(argv[i], "--light")) {
             float v[12];
             for (int k = 0; k < 12; ++k) v[k] = static_cast<float>(std::atof(next(k + 1)));
@@ -139,10 +141,16 @@ int main(int argc, char **argv)
         const uint32_t resumed_at = done;
         auto t0 = std::chrono::steady_clock::now();
         while (done < spp) {
-            const uint32_t n = checkpoint_every ? std::min(checkpoint_every, spp - done) : spp - done;
+            uint32_t n = spp - done;
+            if (checkpoint_every) n = std::min(n, checkpoint_every - done % checkpoint_every);
+            if (preview_every) n = std::min(n, preview_every - done % preview_every);
             renderer.draw(n);
             done += n;
-            if (checkpoint_every && !save_state.empty()) renderer.saveState(save_state);
+            if (checkpoint_every && done % checkpoint_every == 0 && !save_state.empty()) renderer.saveState(save_state);
+            if (preview_every && done % preview_every == 0 && done < spp) {
+                if (!write_ppm(out, renderer.tonemapped(), width, height)) std::fprintf(stderr, "cannot write %s\n", out.c_str());
+                std::printf("preview at %u spp\n", done);
+            }
         }
         renderer.synchronize();
         if (!save_state.empty()) renderer.saveState(save_state);

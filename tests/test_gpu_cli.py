@@ -83,6 +83,10 @@ def test_cli_lights_camera_checkpoint_resume(tmp_path):
     assert "built on the device" in log
     assert np.array_equal(_read_pfm(tmp_path / "c.pfm"), a)  # same tree, same image
 
+    log = _run(common + ["--spp", "12", "--preview-every", "5", "--out", "p.ppm", "--pfm", "p.pfm"], tmp_path)
+    assert "preview at 5 spp" in log and "preview at 10 spp" in log and "preview at 12" not in log
+    assert np.array_equal(_read_pfm(tmp_path / "p.pfm"), a)
+
     dark = _run(["--scene", "room.obj", "--mtl-root", "./", "--width", "32", "--height", "32", "--spp", "2", "--no-light",
                  "--pfm", "d.pfm", "--out", "d.ppm"], tmp_path)
     assert "2 spp" in dark and not _read_pfm(tmp_path / "d.pfm").any()
