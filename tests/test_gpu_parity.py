@@ -252,6 +252,7 @@ def test_sample_surface_matches_oracle(pt, ob):
         ok = (np.allclose(wi[i], owi, atol=2e-4, rtol=2e-3) and np.isclose(pdf[i], opdf, rtol=2e-3, atol=1e-6) and
               np.allclose(f[i], of, rtol=2e-3, atol=1e-6))
         n_bad += 0 if ok else 1
+    print(f"BSDF samples outside tolerance: {n_bad} of {n_checked}; lobe mismatches {n_lobe_mismatch}")
     assert n_checked > 0.8 * n
     assert n_lobe_mismatch <= n * 2e-4
     # Ill-conditioned samples (grazing microfacet normals, near-TIR refraction) amplify ulp differences.
