@@ -48,7 +48,7 @@ SAMPLE_BYTES = 16                      # one radiance sample per path (read by a
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--steps", type=int, default=40)
     p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--scene", default="Box")
     p.add_argument("--width", type=int, default=1920)
