@@ -113,6 +113,23 @@ def test_random_soup_same_tree(pt):
     _assert_same_tree(pt, pt.Scene.from_arrays(**_soup(tris)))
 
 
+def test_flat_and_sliver_geometry_same_tree(pt):
+    # a regular grid in the plane z = 0 (one centroid axis has no extent, many centroids share coordinates)
+    n = 96
+    xs, ys = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32))
+    p00 = np.stack([xs, ys, np.zeros_like(xs)], -1).reshape(-1, 3)
+    a = np.stack([p00, p00 + [1, 0, 0], p00 + [0, 1, 0]], 1)
+    b = np.stack([p00 + [1, 0, 0], p00 + [1, 1, 0], p00 + [0, 1, 0]], 1)
+    _assert_same_tree(pt, pt.Scene.from_arrays(**_soup(np.concatenate([a, b]))))
+    # long slivers crossing the whole scene, zero-area triangles among them
+    rng = np.random.default_rng(2)
+    c = rng.uniform(-1, 1, (3000, 1, 3)).astype(np.float32)
+    d = rng.normal(size=(3000, 1, 3)).astype(np.float32) * 5
+    sl = np.concatenate([c - d, c + d, c + rng.normal(size=(3000, 1, 3)).astype(np.float32) * 1e-3], 1)
+    sl[::50, 2] = sl[::50, 1]  # degenerate: two corners coincide
+    _assert_same_tree(pt, pt.Scene.from_arrays(**_soup(sl)))
+
+
 def test_render_through_the_device_built_tree(pt):
     ids_ref = hit_fixture("Veggie", 256, 256, 0)["ids"]
     scene = pt.Scene.from_arrays(**scene_arrays("Veggie"))
