@@ -1359,11 +1359,14 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
                    Regions regions, PathQueue q, const ExtendOutput &out, TraversalCounters tc, uint32_t n_nodes,
                    bool scene_in_lds)
 {
-    // Idle lanes that trigger a refill from the wave's region (tunable for experiments).
-    static const uint32_t refill_at = [] {
+    // Idle lanes that trigger a refill from the wave's region: 16 when the tree is read from LDS, 32 when
+    // nearly all of it comes from L2 / HBM (a refill stalls the wave on the new rays' loads, and a wave that
+    // waits for node fetches anyway loses less by running thinner for a while: +7 % on 10 M triangles).
+    // PT_REFILL_AT: tuning experiments only.
+    static const int refill_env = [] {
         const char *e = std::getenv("PT_REFILL_AT");
-        int v = e ? std::atoi(e) : 16;
-        return static_cast<uint32_t>(v < 1 ? 1 : (v > 64 ? 64 : v));
+        const int v = e ? std::atoi(e) : 0;
+        return v < 0 ? 0 : (v > 64 ? 64 : v);
     }();
     const bool render = out.render;
     const uint32_t primary = out.primary_of ? 1u : 0u;
@@ -1385,6 +1388,8 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds);
     const int lds_mode = plan.mode;
     const uint32_t n_lds_nodes = plan.n_lds_nodes;
+    const uint32_t refill_at = refill_env ? static_cast<uint32_t>(refill_env)
+                                          : ((lds_mode == 0 || (lds_mode == 1 && n_lds_nodes < n_nodes / 8u)) ? 32u : 16u);
     const size_t lds_bytes = plan.bytes;
 #define PT_LAUNCH_EXTEND2(C, E, L, R, T)                                                                           \
     do {                                                                                                          \

@@ -6,7 +6,7 @@ def run(env_extra, args, label):
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])
         k = d["roofline"]["kernels"]
-        print(f"{label}: {d['value']:.0f} Mpaths/s  extend {k['extend']['ms_total']/k['extend']['launches']*1e3:.0f} us  shade {k['shade']['ms_total']/k['shade']['launches']*1e3:.0f} us /launch; gates {d['gates']['primary_hit_ids_bit_exact_vs_reference']}", flush=True)
+        print(f"{label}: {d['value']:.0f} Mpaths/s  extend {k['extend']['ms_total']/k['extend']['launches']*1e3:.0f} us  shade {k['shade']['ms_total']/k['shade']['launches']*1e3:.0f} us /launch; gates {d['gates'].get('primary_hit_ids_bit_exact_vs_reference')}", flush=True)
     except Exception:
         # A failed GPU run ends the whole sweep: nothing more is started on the card.
         print("failed", label, out.stderr[-800:], flush=True)
