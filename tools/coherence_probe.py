@@ -15,6 +15,8 @@ import pathtracer_amd as pt  # noqa: E402
 
 scene_name = sys.argv[1] if len(sys.argv) > 1 else "Box"
 scene = pt.Scene.load_npz(os.path.join(ROOT, "tests", "golden", "scenes", scene_name + ".npz"))
+if len(sys.argv) > 2:  # instanced on an N^3 lattice
+    scene = scene.instance_lattice(10, int(sys.argv[2]))
 W, H = 1920, 1080
 r = pt.Renderer(scene, pt.Camera(resolution=(W, H)), max_depth=8, iterations_per_batch=4)
 r.set_exact_readbacks(False)
