@@ -64,7 +64,12 @@ typedef struct {
                                       reference's triangle order (frag:391-416)         */
     uint32_t iterations_per_batch; /* samples per pixel in flight at once; 0 = auto     */
     uint32_t profile;              /* bit 0: time every launch with HIP events; bit 1:
-                                      count BVH nodes / triangle tests (both slower)    */
+                                      count BVH nodes / triangle tests (both slower);
+                                      bit 2: evaluate the BSDF at the surface a path's last
+                                      allowed segment ends on, as frag:884-895 does, so that
+                                      pt_stats.nan_samples also counts the non-finite samples
+                                      born there (they add zero to the image either way;
+                                      one more shade launch per batch)                  */
     uint32_t emulate_rgba8;        /* 1: beside the float sum, keep the reference's own
                                       accumulator: an 8-bit RGBA texel per pixel updated as
                                       (accum*it + sample)/(it+1) and re-quantised every

@@ -21,6 +21,9 @@
  *           rgba8    as shipped: RGBA8 feedback accumulation, ITERS iterations
  *           float    RGBA32F accumulation target, shader untouched
  *           float0   RGBA32F target + non-finite pass colour replaced by 0
+ *           post     float0, then the reference's post pass (post.frag.glsl) drawn once more
+ *                    into an RGBA8 texture; OUT.bin = the float image followed by
+ *                    WIDTH*HEIGHT*4 bytes of what the post pass drew
  *     env: PT_REFERENCE_DIR (default /root/reference)
  *          MESA_GL_VERSION_OVERRIDE=4.6 MESA_GLSL_VERSION_OVERRIDE=460 are set
  *          here if absent (llvmpipe stops at 4.5 and rejects "#version 460").
@@ -212,7 +215,7 @@ static GLuint buffer_texture(GLenum unit, GLenum format, const void *data, size_
 int main(int argc, char **argv)
 {
     if (argc != 8) {
-        fprintf(stderr, "usage: %s SCENE.bin OUT.bin WIDTH HEIGHT ids|tn|rgba8|float|float0 ITERS DEPTH\n", argv[0]);
+        fprintf(stderr, "usage: %s SCENE.bin OUT.bin WIDTH HEIGHT ids|tn|rgba8|float|float0|post ITERS DEPTH\n", argv[0]);
         return 2;
     }
     const char *scene_path = argv[1], *out_path = argv[2], *mode = argv[5];
@@ -220,8 +223,9 @@ int main(int argc, char **argv)
     g_height = atoi(argv[4]);
     const int iters = atoi(argv[6]), depth = atoi(argv[7]);
     const int debug_pass = !strcmp(mode, "ids") || !strcmp(mode, "tn");
-    const int float_target = debug_pass || !strcmp(mode, "float") || !strcmp(mode, "float0");
-    if (!debug_pass && strcmp(mode, "rgba8") && strcmp(mode, "float") && strcmp(mode, "float0")) die("bad mode");
+    const int post_dump = !strcmp(mode, "post");
+    const int float_target = debug_pass || !strcmp(mode, "float") || !strcmp(mode, "float0") || post_dump;
+    if (!debug_pass && !post_dump && strcmp(mode, "rgba8") && strcmp(mode, "float") && strcmp(mode, "float0")) die("bad mode");
     setenv("MESA_GL_VERSION_OVERRIDE", "4.6", 0);
     setenv("MESA_GLSL_VERSION_OVERRIDE", "460", 0);
     const char *ref = getenv("PT_REFERENCE_DIR");
@@ -307,7 +311,7 @@ int main(int argc, char **argv)
             snprintf(bound, sizeof bound, "i < %d;", depth);
             frag = replace_once(frag, "i < 10;", bound);
         }
-        if (!strcmp(mode, "float0"))
+        if (!strcmp(mode, "float0") || post_dump)
             frag = replace_once(frag, "vec3 passCol = attenuation * intensity;",
                                 "vec3 passCol = attenuation * intensity;\n"
                                 "    if (any(isnan(passCol)) || any(isinf(passCol))) passCol = vec3(0.f);");
@@ -426,6 +430,37 @@ int main(int argc, char **argv)
     glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, float_target ? GL_FLOAT : GL_UNSIGNED_BYTE, pixels);
     FILE *of = fopen(out_path, "wb");
     if (!of || fwrite(pixels, 1, bytes, of) != bytes) die("cannot write output");
+    if (post_dump) {
+        /* The post pass of renderer.cpp:141-147 once more, into a texture that can be read back (the
+         * reference draws it to the window's RGBA8 back buffer). */
+        GLuint pfbo, ptex;
+        glGenFramebuffers(1, &pfbo);
+        glBindFramebuffer(GL_FRAMEBUFFER, pfbo);
+        glActiveTexture(GL_TEXTURE7);
+        glGenTextures(1, &ptex);
+        glBindTexture(GL_TEXTURE_2D, ptex);
+        glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA8, g_width, g_height, 0, GL_RGBA, GL_UNSIGNED_BYTE, NULL);
+        glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+        glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+        glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, ptex, 0);
+        glDrawBuffers(1, bufs);
+        if (glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) die("post framebuffer incomplete");
+        glViewport(0, 0, g_width, g_height);
+        glClear(GL_COLOR_BUFFER_BIT);
+        glUseProgram(post_prog);
+        glActiveTexture(GL_TEXTURE3);
+        glBindTexture(GL_TEXTURE_2D, accum);
+        glDrawArrays(GL_TRIANGLES, 0, 3);
+        glUseProgram(0);
+        glFinish();
+        glActiveTexture(GL_TEXTURE7);
+        glBindTexture(GL_TEXTURE_2D, ptex);
+        size_t pbytes = (size_t)g_width * g_height * 4;
+        void *ppix = malloc(pbytes);
+        glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_UNSIGNED_BYTE, ppix);
+        if (glGetError() != GL_NO_ERROR) die("GL error in the post dump");
+        if (fwrite(ppix, 1, pbytes, of) != pbytes) die("cannot write output");
+    }
     fclose(of);
     printf("seconds=%.6f\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
     return 0;

@@ -30,13 +30,19 @@ def write_scene(path, arrays, eye, forward, up, right):
 
 def run(arrays, cam, width, height, mode, iters=1, depth=10):
     """cam = (eye, forward, up, right).  For the debug modes 'ids' / 'tn', `depth` is the iteration index.
-    Returns (array HxWx4, seconds)."""
+    Returns (array HxWx4, seconds); for mode 'post' the array is a pair (float image, what post.frag drew as uint8)."""
     with tempfile.TemporaryDirectory() as tmp:
         sp, op = os.path.join(tmp, "scene.bin"), os.path.join(tmp, "out.bin")
         write_scene(sp, arrays, *cam)
         out = subprocess.run([HARNESS, sp, op, str(width), str(height), mode, str(iters), str(depth)],
                              check=True, capture_output=True, text=True)
         secs = float(re.search(r"seconds=([0-9.]+)", out.stdout).group(1))
-        dt = np.uint8 if mode == "rgba8" else np.float32
-        img = np.fromfile(op, dt).reshape(height, width, 4)
+        if mode == "post":
+            raw = np.fromfile(op, np.uint8)
+            n = width * height * 4
+            img = (raw[:4 * n].view(np.float32).reshape(height, width, 4).copy(),
+                   raw[4 * n:].reshape(height, width, 4).copy())
+        else:
+            dt = np.uint8 if mode == "rgba8" else np.float32
+            img = np.fromfile(op, dt).reshape(height, width, 4)
     return img, secs

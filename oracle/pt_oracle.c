@@ -212,7 +212,7 @@ void oracle_trace(const oracle_scene *sc, uint64_t n, const float *origins, cons
                   float *t_out, int32_t *id_out)
 {
     float *inv = make_light_inverses(sc);
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(dynamic, 8)
     for (int64_t i = 0; i < (int64_t)n; ++i) {
         float tp;
         hit_t h = intersect_scan(sc, inv, ld3(origins + 3 * i), ld3(dirs + 3 * i), &tp);
@@ -229,7 +229,7 @@ void oracle_trace(const oracle_scene *sc, uint64_t n, const float *origins, cons
  * comparisons. */
 void oracle_poisoned(const oracle_scene *sc, uint64_t n, const float *origins, const float *dirs, uint8_t *flags)
 {
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(dynamic, 8)
     for (int64_t r = 0; r < (int64_t)n; ++r) {
         v3 o = ld3(origins + 3 * r), d = ld3(dirs + 3 * r);
         uint8_t bad = 0;

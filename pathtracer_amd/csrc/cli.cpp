@@ -156,12 +156,12 @@ int main(int argc, char **argv)
         if (!save_state.empty()) renderer.saveState(save_state);
         double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         pt_stats st = renderer.stats();
-        const double new_paths = static_cast<double>(done - resumed_at) * width * height;  // segments count this run only
+        const double new_paths = static_cast<double>(done - resumed_at) * width * height;  // what this run traced
         std::printf("%zu triangles, %u BVH nodes (depth %u, built on the %s in %.1f ms), %ux%u, %u spp, depth %u: %.3f s, "
                     "%.1f Mpaths/s, %.2f segments/path\n",
                     scene.m_indices.size(), st.n_nodes, st.bvh_depth, st.bvh_builder ? "device" : "host", st.bvh_build_ms,
                     width, height, done, depth, secs,
-                    new_paths / secs / 1e6, new_paths > 0 ? static_cast<double>(st.segments) / new_paths : 0.0);
+                    new_paths / secs / 1e6, st.paths > 0 ? static_cast<double>(st.segments) / static_cast<double>(st.paths) : 0.0);
         if (!write_ppm(out, renderer.tonemapped(), width, height)) {
             std::fprintf(stderr, "cannot write %s\n", out.c_str());
             return 1;

@@ -105,8 +105,9 @@ uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t 
                                bool scene_in_lds);
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
-                  const float4 *hit_list, PathQueue out, float4 *samples /* receives the NaN sample of a path whose throughput went non-finite */,
-                  uint32_t sample_tag, const DeviceCamera *primary_of /* as in ExtendOutput, may be null */);
+                  const float4 *hit_list, PathQueue out, float4 *samples /* receives the sample of a path whose ray went non-finite */,
+                  uint32_t sample_tag, const DeviceCamera *primary_of /* as in ExtendOutput, may be null */,
+                  bool final_bounce /* the hits of the last allowed segment: nothing survives, only non-finite samples are written */);
 
 // The sample buffer is never cleared: a path that ends on a light writes (radiance, tag) with the tag of its
 // batch, and a slot whose w lane does not carry this batch's tag counts as a zero sample (a path that escaped).

@@ -83,11 +83,18 @@ __device__ __forceinline__ float rng_next(uint32_t &sx, uint32_t &sy)
 
 // ---------------------------------------------------------------- raygen
 
+// The word stored beside a ray (PathQueue::lt).  Its magnitude is the distance at which the ray meets the
+// scene's one light, or a quiet NaN when it does not (or when the scene has another number of lights); its
+// sign bit marks a path whose throughput is no longer finite in every channel (see k_shade).
+constexpr uint32_t kNoLightBits = 0x7FC00000u;
+constexpr uint32_t kPoisonBit = 0x80000000u;
+
 // frag:363-382 for one light: distance along the ray to the light's rectangle,
-// -1 when the ray does not meet it (from behind, beside, or never).
+// NaN when the ray does not meet it (from behind, beside, or never).
 // Rows evaluated ((m0*x + m1*y) + m2*z) + m3*w, as in test_lights below.
 __device__ __forceinline__ float light_distance(const DeviceLight &L, f3 o, f3 d)
 {
+    const float none = __uint_as_float(kNoLightBits);
     const float *m = L.inv;
     const float lox = ((m[0] * o.x + m[4] * o.y) + m[8] * o.z) + m[12] * 1.f;
     const float loy = ((m[1] * o.x + m[5] * o.y) + m[9] * o.z) + m[13] * 1.f;
@@ -96,12 +103,12 @@ __device__ __forceinline__ float light_distance(const DeviceLight &L, f3 o, f3 d
     const float ldy = ((m[1] * d.x + m[5] * d.y) + m[9] * d.z) + m[13] * 0.f;
     const float ldz = ((m[2] * d.x + m[6] * d.y) + m[10] * d.z) + m[14] * 0.f;
     const float dt = -ldz;
-    if (dt < 0.f) return -1.f;
+    if (dt < 0.f) return none;
     const float tl = loz / dt;
-    if (tl < 0.f) return -1.f;
+    if (tl < 0.f) return none;
     const float px = lox + ldx * tl, py = loy + ldy * tl;
-    if (!(fabsf(px) <= 0.5f && fabsf(py) <= 0.5f)) return -1.f;
-    return tl;  // finite and >= 0 here: an infinite or NaN tl fails the rectangle test
+    if (!(fabsf(px) <= 0.5f && fabsf(py) <= 0.5f)) return none;
+    return fabsf(tl);  // finite and >= 0 here (an infinite or NaN tl fails the rectangle test); -0 becomes +0
 }
 
 // Which pixel a path slot of an iteration renders.  Consecutive slots are
@@ -229,6 +236,13 @@ __device__ __forceinline__ void test_lights(const SceneView &sc, f3 o, f3 d, flo
     }
 }
 
+// A path whose throughput has a non-finite channel and that ends without reaching a light: the reference's
+// sample is attenuation * vec3(0) (frag:901), NaN in exactly those channels.
+__device__ __forceinline__ void write_poisoned_sample(float4 *__restrict__ samples, float4 p2, uint32_t sample_tag)
+{
+    samples[__float_as_uint(p2.w)] = make_float4(p2.x * 0.f, p2.y * 0.f, p2.z * 0.f, __uint_as_float(sample_tag));
+}
+
 // The hit list of a region has two ends: purely diffuse surfaces are appended
 // upwards from the region's first slot, all other surfaces downwards from its
 // last, so that the shade kernel's waves mostly see one kind of material.
@@ -288,6 +302,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
                 samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, __uint_as_float(sample_tag));
             } else {
                 append = code >= 0 && last_segment == 0u;
+                if (!append && !primary && (__float_as_uint(q.lt[i]) & kPoisonBit)) write_poisoned_sample(samples, q.p2[i], sample_tag);
             }
         }
         if (RENDER)
@@ -386,7 +401,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
         float ix = 0.f, iy = 0.f, iz = 0.f, cnx = 0.f, cny = 0.f, cnz = 0.f, cfx = 0.f, cfy = 0.f, cfz = 0.f;
         bool negx = false, negy = false, negz = false;
         Hit h{__builtin_inff(), -1};
-        float ltv = -1.f;  // distance to the light when known beforehand, else < 0
+        float ltv = __uint_as_float(kNoLightBits);  // the word beside the ray: |ltv| = distance to the light or NaN, sign = poisoned path
         int node = 0, sp = 0;
 
         for (;;) {
@@ -444,8 +459,8 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                         negz = iz < 0.f;
                         // one-light scenes: the light's distance, known since the ray was made, is the limit
                         // the traversal starts with (a surface beyond the light cannot change the outcome)
-                        ltv = USE_LT ? q.lt[slot] : -1.f;
-                        h.t = ltv >= 0.f ? ltv : __builtin_inff();
+                        ltv = (USE_LT || (RENDER && !primary)) ? q.lt[slot] : __uint_as_float(kNoLightBits);
+                        h.t = (USE_LT && fabsf(ltv) >= 0.f) ? fabsf(ltv) : __builtin_inff();
                         h.id = -1;
                         node = 0;
                         sp = 0;
@@ -559,7 +574,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 other = h.id >= 0 && (h.id & kClassBit) != 0;
                 if (USE_LT) {
                     // the light wins unless a surface lies strictly in front of it (frag:427: reject if tl > t)
-                    if (ltv >= 0.f && !(ltv > h.t)) hit_code = -2;
+                    if (fabsf(ltv) >= 0.f && !(fabsf(ltv) > h.t)) hit_code = -2;
                 } else {
                     test_lights(sc, o, d, hit_t, hit_code);
                 }
@@ -574,6 +589,8 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                     samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, __uint_as_float(sample_tag));
                 } else {
                     append = hit_code >= 0 && last_segment == 0u;
+                    // a poisoned path that escapes, or whose last allowed segment ends on a surface
+                    if (!append && (__float_as_uint(ltv) & kPoisonBit)) write_poisoned_sample(samples, q.p2[slot], sample_tag);
                 }
                 active = false;
             }
@@ -958,11 +975,13 @@ __device__ __forceinline__ Material load_material(const SceneView &sc, uint32_t 
 // compaction of the surviving paths into the wave's own region of the next
 // queue: one ballot + prefix rank per 64 hits, no atomics.  A path that dies
 // here (pdf <= 0, a lobe that returned without a direction, zero throughput)
-// simply is not written: its sample slot already holds zero.
+// simply is not written: its sample slot already holds zero.  final_bounce: the
+// hits are those of the paths' last allowed segment; nothing survives, the BSDF
+// is evaluated only because a non-finite value it produces is the path's sample.
 __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, Regions rg, PathQueue in,
                                                    const float4 *__restrict__ hit_list, PathQueue out,
                                                    float4 *__restrict__ samples, uint32_t sample_tag,
-                                                   DeviceCamera cam, uint32_t primary)
+                                                   DeviceCamera cam, uint32_t primary, uint32_t final_bounce)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
@@ -1009,6 +1028,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
             j = (full1 << 6) + lane;
         }
         bool alive = false;
+        uint32_t flag = 0u;  // kPoisonBit for a survivor whose throughput is not finite in every channel
         float4 o0, o1, o2;
         if (take0 || take1) {
             const float4 rec = hit_list[region_base + (take1 ? last_slot - j : j)];
@@ -1045,29 +1065,38 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
                     const float cs = fabsf(dotm(nrm, r.wi));
                     att = mk(att.x * (r.f.x * cs), att.y * (r.f.y * cs), att.z * (r.f.z * cs));
                     if (r.pdf <= 0.f) {
-                        dead = true;
+                        dead = true;  // frag:890-894: attenuation = vec3(0), whatever it was
                     } else {
                         const float ipdf = sdiv(1.f, r.pdf);
                         att = mk(att.x * ipdf, att.y * ipdf, att.z * ipdf);
                         // A path whose throughput is exactly zero can only ever add zero.
                         if (att.x == 0.f && att.y == 0.f && att.z == 0.f) dead = true;
-                        // A throughput that has gone NaN / inf in all channels stays so: whatever the path
-                        // meets later, the reference's sample is attenuation * intensity = non-finite
-                        // (frag:901; NaN * 0 for a path that never reaches a light).  The path ends here
-                        // with that sample; the accumulate kernel counts it and adds zero to the float image.
-                        if (!isfinite(att.x) && !isfinite(att.y) && !isfinite(att.z)) {
-                            dead = true;
-                            const float nan = __builtin_nanf("");
-                            samples[__float_as_uint(c.w)] = make_float4(nan, nan, nan, __uint_as_float(sample_tag));
-                        }
                     }
                 }
                 if (!dead) {
-                    alive = true;
                     const f3 no = mk(p.x + r.wi.x * 0.0001f, p.y + r.wi.y * 0.0001f, p.z + r.wi.z * 0.0001f);
-                    o0 = make_float4(no.x, no.y, no.z, r.wi.x);
-                    o1 = make_float4(r.wi.y, r.wi.z, __uint_as_float(sx), __uint_as_float(sy));
-                    o2 = make_float4(att.x, att.y, att.z, c.w);
+                    // The reference never ends a path because its throughput went NaN or inf (frag:888-897): the
+                    // path goes on, and its sample is attenuation * intensity (frag:901) -- non-finite in the
+                    // affected channels wherever it ends, unless a later bounce zeroes the attenuation
+                    // (pdf <= 0).  Such a path is traced on with its flag set beside the ray, so that the kernel
+                    // that ends it writes that sample.  A ray that is itself non-finite (the NaN tangent frame of
+                    // frag:171) turns everything after it NaN: its sample is written here.
+                    const bool poisoned = !(isfinite(att.x) && isfinite(att.y) && isfinite(att.z));
+                    const bool bad_ray = !(isfinite(no.x) && isfinite(no.y) && isfinite(no.z) && isfinite(r.wi.x) &&
+                                           isfinite(r.wi.y) && isfinite(r.wi.z));
+                    if (bad_ray) {
+                        const float nan = __builtin_nanf("");
+                        samples[__float_as_uint(c.w)] = make_float4(nan, nan, nan, __uint_as_float(sample_tag));
+                    } else if (final_bounce) {
+                        // the path's last allowed segment ended on this surface: intensity stays vec3(0)
+                        if (poisoned) write_poisoned_sample(samples, make_float4(att.x, att.y, att.z, c.w), sample_tag);
+                    } else {
+                        alive = true;
+                        o0 = make_float4(no.x, no.y, no.z, r.wi.x);
+                        o1 = make_float4(r.wi.y, r.wi.z, __uint_as_float(sx), __uint_as_float(sy));
+                        o2 = make_float4(att.x, att.y, att.z, c.w);
+                        flag = poisoned ? kPoisonBit : 0u;
+                    }
                 }
             }
         }
@@ -1079,8 +1108,9 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
             out.p0[dst] = o0;
             out.p1[dst] = o1;
             out.p2[dst] = o2;
-            if (sc.n_lights == 1u)
-                out.lt[dst] = light_distance(sc.lights[0], mk(o0.x, o0.y, o0.z), mk(o0.w, o1.x, o1.y));
+            const float tl = sc.n_lights == 1u ? light_distance(sc.lights[0], mk(o0.x, o0.y, o0.z), mk(o0.w, o1.x, o1.y))
+                                               : __uint_as_float(kNoLightBits);
+            out.lt[dst] = __uint_as_float(__float_as_uint(tl) | flag);
         }
         out_n += static_cast<uint32_t>(__popcll(live));
       }
@@ -1431,10 +1461,11 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
                   const float4 *hit_list, PathQueue out, float4 *samples, uint32_t sample_tag,
-                  const DeviceCamera *primary_of)
+                  const DeviceCamera *primary_of, bool final_bounce)
 {
     hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g, kBlock, "PT_SHADE_PER_CU")), dim3(kBlock), 0, s, scene, regions, in, hit_list, out,
-                       samples, sample_tag, primary_of ? *primary_of : DeviceCamera{}, primary_of ? 1u : 0u);
+                       samples, sample_tag, primary_of ? *primary_of : DeviceCamera{}, primary_of ? 1u : 0u,
+                       final_bounce ? 1u : 0u);
 }
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,

@@ -46,6 +46,13 @@ int fail(int code, const std::string &msg)
         if (!(cond)) return fail(PT_ERR_INVALID, msg); \
     } while (0)
 
+// Entry points that touch the path buffers refuse a renderer whose last pt_resize left it without any.
+#define PT_USABLE(r)                                                                                              \
+    do {                                                                                                          \
+        if (!(r)->usable)                                                                                         \
+            return fail(PT_ERR_STATE, "the renderer has no image buffers (a pt_resize failed); call pt_resize again"); \
+    } while (0)
+
 double now_ms()
 {
     using namespace std::chrono;
@@ -111,6 +118,7 @@ struct pt_renderer {
     pt::DeviceCamera cam{};
 
     // path state
+    bool usable = true;  // false after a pt_resize that could neither get the new buffers nor restore the old size
     uint32_t width = 0, height = 0, batch_iterations = 1;
     size_t capacity = 0;
     pt::PathQueue q[2] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
@@ -229,11 +237,10 @@ uint32_t gcd_u32(uint32_t a, uint32_t b)
     return a;
 }
 
-int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
+// Samples per pixel that share a batch at this image size; 0 when the image has more pixels than path slots
+// can be numbered (32 bits).
+uint32_t batch_iterations_for(const pt_renderer *r, uint32_t width, uint32_t height)
 {
-    free_paths(r);
-    r->width = width;
-    r->height = height;
     const size_t n_pixels = static_cast<size_t>(width) * height;
     uint32_t k = r->cfg.iterations_per_batch;
     if (k == 0) {
@@ -242,9 +249,20 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         // buffers), at most 32 samples per pixel.
         k = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(32, (size_t(64) << 20) / std::max<size_t>(1, n_pixels))));
     }
-    // Path slots are 32-bit.
     while (k > 1 && n_pixels * k >= (size_t(1) << 31)) --k;
-    if (n_pixels * k >= (size_t(1) << 31)) return fail(PT_ERR_INVALID, "resolution too large");
+    return n_pixels * k >= (size_t(1) << 31) ? 0u : k;
+}
+
+// Frees the path buffers and allocates them for width x height.  On failure the renderer holds no (or only
+// part of the) buffers: the caller either restores a size that worked or marks the renderer unusable.
+int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
+{
+    const uint32_t k = batch_iterations_for(r, width, height);
+    if (k == 0) return fail(PT_ERR_INVALID, "resolution too large");  // nothing has been freed yet
+    free_paths(r);
+    r->width = width;
+    r->height = height;
+    const size_t n_pixels = static_cast<size_t>(width) * height;
     r->batch_iterations = k;
     r->capacity = n_pixels * k;
     for (int b = 0; b < 2; ++b) {
@@ -443,8 +461,10 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = q[b & 1], &out = q[(b + 1) & 1];
         // The last surface hit needs no new direction -- except that the reference still evaluates the BSDF
-        // there, and a NaN it produces becomes the path's sample: the 8-bit emulation runs that last shade too.
-        const bool last = (b + 1 == depth) && !r->cfg.emulate_rgba8;
+        // there, and a NaN it produces becomes the path's sample: the 8-bit emulation runs that last shade too,
+        // and so does a renderer asked to count non-finite samples exactly (profile bit 2).
+        const bool final_shade = (b + 1 == depth) && (r->cfg.emulate_rgba8 || (r->cfg.profile & 4u));
+        const bool last = (b + 1 == depth) && !final_shade;
         const int hit_row = static_cast<int>(depth + 1 + b);
         {
             Timed t(r, 1, st);
@@ -456,7 +476,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
             Timed t(r, 2, st);
             pt::launch_shade(st, g, r->view,
                              regions_for(r, n_paths, static_cast<uint32_t>(hit_row), static_cast<int>(b) + 1, d_counts), in, d_hits,
-                             out, d_samples, tag, b == 0 ? &r->cam : nullptr);
+                             out, d_samples, tag, b == 0 ? &r->cam : nullptr, final_shade);
         }
     }
     {
@@ -684,6 +704,15 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
             }
             if (!diffuse) tri.original |= pt::kHitClassBit;
         }
+        // A zero-area triangle has a NaN normal.  The reference's scan "hits" it with every ray (frag:402-413
+        // compare false on NaN); a tree cannot, so under use_bvh such a triangle is made inert: st = -1 / 0 =
+        // -inf is rejected by the first comparison.  (The device builder does the same.)  Scan mode keeps the NaN.
+        if (r->cfg.use_bvh)
+            for (pt::BvhTriangle &tri : bvh.triangles)
+                if (!(std::isfinite(tri.nx) && std::isfinite(tri.ny) && std::isfinite(tri.nz))) {
+                    tri.nx = tri.ny = tri.nz = 0.f;
+                    tri.d0 = -1.f;
+                }
         if ((rc = upload(&r->d_tris, bvh.triangles.data(), bvh.triangles.size() * sizeof(pt::BvhTriangle)))) return rc;
     }
     if (!device_build && (rc = upload(&r->d_shade, shade.data(), shade.size() * sizeof(pt::ShadeTriangle)))) return rc;
@@ -996,6 +1025,7 @@ void pt_destroy(pt_renderer *r)
 int pt_set_camera(pt_renderer *r, const float eye[3], const float forward[3], const float up[3], const float right[3])
 {
     PT_REQUIRE(r && eye && forward && up && right, "pt_set_camera: null argument");
+    PT_USABLE(r);
     PT_HIP(hipSetDevice(r->device));
     for (int k = 0; k < 3; ++k) {
         r->cam.eye[k] = eye[k];
@@ -1010,9 +1040,27 @@ int pt_resize(pt_renderer *r, uint32_t width, uint32_t height)
 {
     PT_REQUIRE(r && width >= 1 && height >= 1, "pt_resize: bad argument");
     PT_HIP(hipSetDevice(r->device));
+    if (batch_iterations_for(r, width, height) == 0) return fail(PT_ERR_INVALID, "pt_resize: resolution too large");
     PT_HIP(sync_streams(r));
+    const uint32_t old_w = r->cfg.width, old_h = r->cfg.height;
+    const bool was_usable = r->usable;
     int rc = alloc_paths(r, width, height);
-    if (rc != PT_OK) return rc;
+    if (rc != PT_OK) {
+        // The old buffers are gone (both sets together may not fit beside each other, so the new ones are
+        // not allocated first).  Go back to the size that worked; if even that fails the renderer refuses
+        // everything but pt_resize / pt_destroy until a resize succeeds.
+        const std::string why = g_last_error;
+        (void)hipGetLastError();
+        r->usable = was_usable && alloc_paths(r, old_w, old_h) == PT_OK && reset_accumulation(r) == PT_OK;
+        if (!r->usable) {
+            free_paths(r);
+            r->width = r->height = 0;
+            r->capacity = 0;
+        }
+        return fail(rc, "pt_resize: " + why + (r->usable ? " (the previous size was restored, accumulation reset)"
+                                                         : " (the renderer has no image buffers now)"));
+    }
+    r->usable = true;
     r->cfg.width = width;
     r->cfg.height = height;
     return reset_accumulation(r);
@@ -1021,6 +1069,7 @@ int pt_resize(pt_renderer *r, uint32_t width, uint32_t height)
 int pt_reset(pt_renderer *r)
 {
     PT_REQUIRE(r, "pt_reset: null argument");
+    PT_USABLE(r);
     PT_HIP(hipSetDevice(r->device));
     return reset_accumulation(r);
 }
@@ -1028,6 +1077,7 @@ int pt_reset(pt_renderer *r)
 int pt_set_partition(pt_renderer *r, uint32_t rank, uint32_t world)
 {
     PT_REQUIRE(r && world >= 1 && rank < world, "pt_set_partition: need rank < world");
+    PT_USABLE(r);
     if (r->cfg.emulate_rgba8 && world != 1)
         return fail(PT_ERR_STATE, "pt_set_partition: the 8-bit running average cannot be partitioned");
     PT_HIP(hipSetDevice(r->device));
@@ -1039,6 +1089,7 @@ int pt_set_partition(pt_renderer *r, uint32_t rank, uint32_t world)
 int pt_render(pt_renderer *r, uint32_t n_iterations)
 {
     PT_REQUIRE(r, "pt_render: null argument");
+    PT_USABLE(r);
     PT_HIP(hipSetDevice(r->device));
     uint32_t left = n_iterations;
     while (left > 0) {
@@ -1054,17 +1105,20 @@ int pt_render(pt_renderer *r, uint32_t n_iterations)
 
 namespace {
 struct StateHeader {
-    char magic[8];  // "PTAMDST1"
+    char magic[8];  // "PTAMDST2"
     uint32_t width, height, max_depth, rank, world, reserved;
     uint64_t local_iterations, paths, scene_hash;
     float fov_y_degrees;
     float eye[3], forward[3], up[3], right[3];
+    uint64_t counters[14];  // the device counters behind pt_stats (segments, non-finite samples, ...), so that
+                            // the statistics of a resumed render cover the whole render like `paths` does
 };
 }  // namespace
 
 int pt_save_state(pt_renderer *r, const char *path)
 {
     PT_REQUIRE(r && path, "pt_save_state: null argument");
+    PT_USABLE(r);
     if (r->d_rgba8) return fail(PT_ERR_STATE, "pt_save_state: not available with emulate_rgba8");
     PT_HIP(hipSetDevice(r->device));
     const size_t n = static_cast<size_t>(r->width) * r->height * 4;
@@ -1073,7 +1127,7 @@ int pt_save_state(pt_renderer *r, const char *path)
     if (rc != PT_OK) return rc;
     StateHeader h;
     std::memset(&h, 0, sizeof(h));
-    std::memcpy(h.magic, "PTAMDST1", 8);
+    std::memcpy(h.magic, "PTAMDST2", 8);
     h.width = r->width;
     h.height = r->height;
     h.max_depth = r->cfg.max_depth;
@@ -1082,6 +1136,7 @@ int pt_save_state(pt_renderer *r, const char *path)
     h.local_iterations = r->local_iterations;
     h.paths = r->paths;
     h.scene_hash = r->scene_hash;
+    PT_HIP(hipMemcpy(h.counters, r->d_counters, sizeof(h.counters), hipMemcpyDeviceToHost));  // pt_read_sum has synchronised
     h.fov_y_degrees = r->cfg.fov_y_degrees;
     for (int k = 0; k < 3; ++k) {
         h.eye[k] = r->cam.eye[k];
@@ -1104,6 +1159,7 @@ int pt_save_state(pt_renderer *r, const char *path)
 int pt_load_state(pt_renderer *r, const char *path)
 {
     PT_REQUIRE(r && path, "pt_load_state: null argument");
+    PT_USABLE(r);
     if (r->d_rgba8) return fail(PT_ERR_STATE, "pt_load_state: not available with emulate_rgba8");
     PT_HIP(hipSetDevice(r->device));
     FILE *f = std::fopen(path, "rb");
@@ -1111,7 +1167,7 @@ int pt_load_state(pt_renderer *r, const char *path)
     StateHeader h;
     const size_t n = static_cast<size_t>(r->width) * r->height * 4;
     std::vector<float> sum(n);
-    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "PTAMDST1", 8) == 0;
+    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "PTAMDST2", 8) == 0;
     const bool fits = ok && h.width == r->width && h.height == r->height;
     ok = fits && std::fread(sum.data(), sizeof(float), n, f) == n && std::fgetc(f) == EOF;
     std::fclose(f);
@@ -1129,6 +1185,7 @@ int pt_load_state(pt_renderer *r, const char *path)
     int rc = reset_accumulation(r);
     if (rc != PT_OK) return rc;
     PT_HIP(hipMemcpyAsync(r->d_sum, sum.data(), n * sizeof(float), hipMemcpyHostToDevice, r->stream));
+    PT_HIP(hipMemcpyAsync(r->d_counters, h.counters, sizeof(h.counters), hipMemcpyHostToDevice, r->stream));
     PT_HIP(sync_streams(r));
     r->local_iterations = h.local_iterations;
     r->paths = h.paths;
@@ -1146,6 +1203,7 @@ int pt_synchronize(pt_renderer *r)
 int pt_read_sum(pt_renderer *r, float *rgba)
 {
     PT_REQUIRE(r && rgba, "pt_read_sum: null argument");
+    PT_USABLE(r);
     PT_HIP(hipSetDevice(r->device));
     PT_HIP(sync_streams(r));  // batches of both streams add to the sum
     PT_HIP(hipMemcpyAsync(rgba, r->d_sum, static_cast<size_t>(r->width) * r->height * sizeof(float4), hipMemcpyDeviceToHost,
@@ -1157,6 +1215,7 @@ int pt_read_sum(pt_renderer *r, float *rgba)
 int pt_read_rgba8(pt_renderer *r, uint8_t *rgba)
 {
     PT_REQUIRE(r && rgba, "pt_read_rgba8: null argument");
+    PT_USABLE(r);
     if (!r->d_rgba8) return fail(PT_ERR_STATE, "pt_read_rgba8: the renderer was created without emulate_rgba8");
     PT_HIP(hipSetDevice(r->device));
     PT_HIP(sync_streams(r));
@@ -1183,6 +1242,7 @@ int pt_read_radiance(pt_renderer *r, float *rgba)
 int pt_read_tonemapped(pt_renderer *r, uint8_t *rgb)
 {
     PT_REQUIRE(r && rgb, "pt_read_tonemapped: null argument");
+    PT_USABLE(r);
     PT_HIP(hipSetDevice(r->device));
     const size_t n = static_cast<size_t>(r->width) * r->height;
     uint8_t *d = nullptr;
@@ -1199,6 +1259,7 @@ int pt_read_tonemapped(pt_renderer *r, uint8_t *rgb)
 int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, float *dirs)
 {
     PT_REQUIRE(r && (ids || t || dirs), "pt_read_hit_ids: null argument");
+    PT_USABLE(r);
     PT_HIP(hipSetDevice(r->device));
     PT_HIP(sync_streams(r));
     const size_t n = static_cast<size_t>(r->width) * r->height;
@@ -1240,6 +1301,7 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
 int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float *dirs, float *t, int32_t *ids)
 {
     PT_REQUIRE(r && (n == 0 || (origins && dirs)), "pt_trace_rays: null argument");
+    PT_USABLE(r);
     PT_HIP(hipSetDevice(r->device));
     PT_HIP(sync_streams(r));
     if (n == 0) return PT_OK;
@@ -1328,6 +1390,7 @@ int pt_set_exact_readbacks(pt_renderer *r, uint32_t enabled)
 int pt_sum_device_ptr(pt_renderer *r, void **dev_ptr)
 {
     PT_REQUIRE(r && dev_ptr, "pt_sum_device_ptr: null argument");
+    PT_USABLE(r);
     PT_HIP(hipSetDevice(r->device));
     PT_HIP(sync_streams(r));  // the caller reads the buffer on a stream of its own
     *dev_ptr = r->d_sum;

@@ -7,6 +7,8 @@ reference rendered); no reference source is stored.
   python tests/golden/make_llvmpipe_fixtures.py ids      # primary hit buffers
   python tests/golden/make_llvmpipe_fixtures.py images   # converged float images (minutes)
   python tests/golden/make_llvmpipe_fixtures.py timing   # llvmpipe throughput table
+  python tests/golden/make_llvmpipe_fixtures.py ids_large  # hit buffers at benchmark sizes, a moved camera (minutes)
+  python tests/golden/make_llvmpipe_fixtures.py post     # what post.frag draws from a float image
 """
 import glob
 import json
@@ -34,8 +36,20 @@ def scene_and_cam(name, w, h):
     return s.arrays(), (cam.eye, cam.forward, cam.up, cam.right)
 
 
-def ids_fixture(name, w, h, iteration, full):
+def moved_camera(w, h, moves):
+    """Camera after a sequence of (op, args) moves, e.g. ("orbit", (0.4, 0.1)); axes as Camera::update leaves them."""
+    cam = pt.Camera(resolution=(w, h))
+    cam.update()
+    for op, args in moves:
+        getattr(cam, op)(*args)
+        cam.update()
+    return cam.eye, cam.forward, cam.up, cam.right
+
+
+def ids_fixture(name, w, h, iteration, full, cam=None, tag=""):
     a, c = scene_and_cam(name, w, h)
+    if cam is not None:
+        c = cam
     img, _ = rr.run(a, c, w, h, "ids", 1, iteration)
     ids = img[..., 3].astype(np.int32)
     assert np.array_equal(ids.astype(np.float32), img[..., 3])
@@ -45,7 +59,9 @@ def ids_fixture(name, w, h, iteration, full):
         out["dirs_bits"] = img[..., :3].copy().view(np.uint32)
         out["t_bits"] = tn[..., 0].copy().view(np.uint32)
         out["normal_bits"] = tn[..., 1:].copy().view(np.uint32)
-    path = os.path.join(OUT, f"hit_{name}_{w}x{h}_it{iteration}.npz")
+    if cam is not None:
+        out["camera"] = np.stack(cam).astype(np.float32)  # eye, forward, up, right handed to the shader
+    path = os.path.join(OUT, f"hit_{name}_{w}x{h}_it{iteration}{tag}.npz")
     np.savez_compressed(path, **out)
     print(name, w, h, iteration, "geometry", int((ids >= 0).sum()), "light", int((ids <= -2).sum()),
           "miss", int((ids == -1).sum()), os.path.getsize(path), flush=True)
@@ -61,6 +77,21 @@ def main():
         ids_fixture("Box", 192, 108, 3, full=True)  # non-square aspect
         for n in ("Box", "Veggie"):
             ids_fixture(n, 1920, 1080, 0, full=False)
+    elif what == "ids_large":
+        # the remaining benchmark configurations at their own sizes
+        for n in ("Box_Transmission", "Box_TransmissionSphere", "Box_Anisotropic", "AnisotropicTest"):
+            ids_fixture(n, 1920, 1080, 0, full=False)
+        # a pose the mouse callbacks of main.cpp:75-106 could have produced: orbit, then zoom, then pan
+        moves = [("orbit", (0.4, 0.1)), ("zoom", (0.7,)), ("pan", (0.3, -0.2))]
+        ids_fixture("Box", 640, 360, 2, full=True, cam=moved_camera(640, 360, moves), tag="_moved")
+        ids_fixture("Veggie", 3840, 2160, 0, full=False)
+    elif what == "post":
+        a, c = scene_and_cam("Box", 256, 256)
+        (img, post), _ = rr.run(a, c, 256, 256, "post", 64, 8)
+        path = os.path.join(OUT, "post_Box_256x256_spp64_depth8.npz")
+        np.savez_compressed(path, mean_rgb=img[..., :3].astype(np.float32), post_rgba8=post, spp=np.int32(64),
+                            depth=np.int32(8))
+        print("post", img[..., :3].mean(axis=(0, 1)), post[..., :3].mean(axis=(0, 1)), os.path.getsize(path), flush=True)
     elif what == "images":
         jobs = [("Box", 8), ("Box", 5), ("Box_Anisotropic", 8), ("AnisotropicTest", 8), ("Box_Transmission", 8),
                 ("Box_TransmissionSphere", 8), ("Veggie", 8)]

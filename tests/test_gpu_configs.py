@@ -1,0 +1,159 @@
+"""The benchmark configurations at their own sizes, a moved camera and another
+field of view, on a real MI355X through the C ABI.
+
+Reference fixtures (llvmpipe runs of the reference's shader): the four
+transmission / anisotropy scenes at 1920x1080, Veggie at 3840x2160, Box from a
+pose reached by orbit + zoom + pan.  Where the reference cannot serve (its field
+of view is a literal, frag:306; ten million triangles take it hours) the
+oracle, pinned to the reference by those fixtures, is the comparison."""
+import ctypes as C
+import ctypes.util
+import os
+
+import numpy as np
+import pytest
+
+from conftest import LLVMPIPE, default_camera_axes, hit_fixture, scene_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(pt, name):
+    return pt.Scene.from_arrays(**scene_arrays(name))
+
+
+def _tan_half_fov(degrees):
+    """tan(FOVY * 0.5f) with FOVY = degrees * PI / 180.f, every step in f32 and libm's tanf (frag:306,315)."""
+    libm = C.CDLL(ctypes.util.find_library("m"))
+    libm.tanf.restype = C.c_float
+    libm.tanf.argtypes = [C.c_float]
+    fovy = np.float32(np.float32(np.float32(degrees) * np.float32(3.14159265358979323)) / np.float32(180.0))
+    return np.float32(libm.tanf(C.c_float(float(np.float32(fovy * np.float32(0.5))))))
+
+
+def test_tan_half_fov_helper_reproduces_the_shader_constant():
+    assert _tan_half_fov(19.5).view(np.uint32) == 0x3E2FF494
+
+
+@pytest.mark.parametrize("name", ["Box_Transmission", "Box_TransmissionSphere", "Box_Anisotropic", "AnisotropicTest"])
+def test_primary_hit_buffer_bit_exact_vs_reference_1080p_other_configs(pt, name):
+    fx = hit_fixture(name, 1920, 1080)["ids"]
+    r = pt.Renderer(_scene(pt, name), pt.Camera(resolution=(1920, 1080)))
+    ids, _, _ = r.read_hit_ids(0)
+    r.close()
+    assert np.array_equal(ids, fx), f"{int((ids != fx).sum())} hit codes differ"
+
+
+def test_moved_camera_against_the_reference(pt):
+    """A pose the mouse callbacks could have produced (main.cpp:75-106 -> camera.cpp:32-86): orbit, zoom,
+    pan, with Camera::update after each.  The fixture holds the axes that went to the reference's shader
+    and what it rendered at 640x360, iteration 2: hit codes, t bits and direction bits."""
+    fx = np.load(os.path.join(LLVMPIPE, "hit_Box_640x360_it2_moved.npz"))
+    cam = pt.Camera(resolution=(640, 360))
+    cam.update()
+    for op, args in (("orbit", (0.4, 0.1)), ("zoom", (0.7,)), ("pan", (0.3, -0.2))):
+        getattr(cam, op)(*args)
+        cam.update()
+    axes = np.stack([cam.eye, cam.forward, cam.up, cam.right]).astype(np.float32)
+    assert np.array_equal(axes.view(np.uint32), fx["camera"].view(np.uint32)), "Camera no longer produces the fixture's pose"
+    assert not np.allclose(axes[0], default_camera_axes()[0])
+    for use_bvh in (True, False):
+        r = pt.Renderer(_scene(pt, "Box"), cam, use_bvh=use_bvh)
+        ids, t, dirs = r.read_hit_ids(2, True, True)
+        r.close()
+        assert np.array_equal(ids, fx["ids"]), f"{int((ids != fx['ids']).sum())} hit codes differ"
+        assert np.array_equal(dirs.view(np.uint32), fx["dirs_bits"])
+        geo = fx["ids"] >= 0
+        assert geo.sum() > 100_000
+        assert np.array_equal(t.view(np.uint32)[geo], fx["t_bits"][geo])
+
+
+@pytest.mark.parametrize("name,fov,w,h", [("Box", 35.0, 320, 200), ("Veggie", 60.0, 200, 320), ("Box_Transmission", 8.0, 256, 144)])
+def test_other_field_of_view_and_pose_against_the_oracle(pt, ob, name, fov, w, h):
+    """The reference's field of view is a literal (frag:306), so another one is compared with the oracle:
+    hit codes, t bits, direction bits, from a camera that was orbited and zoomed; then a short render
+    against the oracle's with the same camera."""
+    cam = pt.Camera(eye=(2.0, 0.5, 11.0), focus=(0.1, 0.0, -0.3), resolution=(w, h))
+    cam.update()
+    cam.orbit(-0.3, 0.2)
+    cam.update()
+    cam.zoom(1.2)
+    cam.update()
+    r = pt.Renderer(_scene(pt, name), cam, fov_y_degrees=fov, max_depth=6)
+    ids, t, dirs = r.read_hit_ids(1, True, True)
+    r.draw(8)
+    img = r.read_radiance()[..., :3]
+    r.close()
+    osc = ob.OracleScene(scene_arrays(name))
+    oc = ob.make_camera(cam.eye, cam.forward, cam.up, cam.right, w, h, tan_half_fov=_tan_half_fov(fov))
+    oid, ot, od = ob.primary(osc, oc, 1)
+    assert (oid >= 0).mean() > 0.2
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(dirs.view(np.uint32), od.view(np.uint32))
+    osum, _ = ob.render(osc, oc, 0, 8, 6, min(16, os.cpu_count() or 1))
+    oimg = osum[..., :3] / 8
+    close = np.isclose(img, oimg, rtol=1e-3, atol=1e-4).all(axis=2).mean()
+    assert close > 0.97, f"only {close:.3f} of the pixels agree with the oracle"
+
+
+def test_veggie_at_3840x2160(pt):
+    """The size of the 4K configuration: hit buffer equals the reference's on all 8.3 M pixels; every pixel
+    gets its samples; two renders agree bit for bit; the batch holds 8 samples per pixel there."""
+    fx = hit_fixture("Veggie", 3840, 2160)["ids"]
+    r = pt.Renderer(_scene(pt, "Veggie"), pt.Camera(resolution=(3840, 2160)), max_depth=8)
+    ids, _, _ = r.read_hit_ids(0)
+    assert np.array_equal(ids, fx), f"{int((ids != fx).sum())} hit codes differ"
+    r.draw(10)  # one full batch and a ragged one
+    a = r.read_sum()
+    st = r.stats()
+    r.reset()
+    r.draw(10)
+    b = r.read_sum()
+    r.close()
+    assert np.array_equal(a, b)
+    assert np.all(a[..., 3] == 10) and np.isfinite(a).all()
+    assert st["paths"] == 3840 * 2160 * 10
+    assert 2.0 < st["segments"] / st["paths"] < 4.5
+    mean = a[..., :3].mean(axis=(0, 1)) / 10
+    assert 0.02 < mean.min() and mean.max() < 0.15
+
+
+def test_ten_million_triangle_scene_rendered_at_3840x2160(pt, ob):
+    """The traversal-stress configuration end to end: Veggie's content instanced on a 19^3 lattice
+    (9 876 970 triangles), tree built on the device, two samples per pixel at 3840x2160.  Sample counts,
+    finiteness and determinism over the whole frame; primary hit codes and t bits against the oracle's
+    linear scan over all triangles on 2 304 pixels spread over the frame."""
+    lat = _scene(pt, "Veggie").instance_lattice(10, 19)
+    a = lat.arrays()
+    assert a["indices"].shape[0] == 9_876_970
+    w, h = 3840, 2160
+    cam = pt.Camera(resolution=(w, h))
+    r = pt.Renderer(lat, cam, max_depth=8)
+    ids, t, dirs = r.read_hit_ids(0, True, True)
+    r.draw(2)
+    s1 = r.read_sum()
+    st = r.stats()
+    r.reset()
+    r.draw(2)
+    s2 = r.read_sum()
+    r.close()
+    assert st["n_triangles"] == 9_876_970 and st["bvh_builder"] == 1
+    assert st["paths"] == w * h * 2
+    assert np.array_equal(s1, s2)
+    assert np.all(s1[..., 3] == 2) and np.isfinite(s1).all()
+    assert s1[..., :3].max() > 0
+    assert 2.0 < st["segments"] / st["paths"] < 6.0
+
+    ys, xs = np.meshgrid(np.arange(22, h, 45), np.arange(37, w, 80), indexing="ij")  # 48 x 48 pixels
+    ys, xs = ys.ravel(), xs.ravel()
+    assert ys.size >= 2000
+    eye = np.tile(np.asarray(cam.eye, np.float32), (ys.size, 1))
+    osc = ob.OracleScene(a)
+    ot, oid = ob.trace(osc, eye, dirs[ys, xs])
+    assert (oid >= 0).sum() > 500 and len(np.unique(oid[oid >= 0])) > 300
+    assert np.array_equal(ids[ys, xs], oid)
+    assert np.array_equal(t[ys, xs].view(np.uint32), ot.view(np.uint32))
+    # the same rays straight from the oracle's camera: the directions above are the reference's
+    _, _, od = ob.primary_dirs_only(osc, ob.make_camera(*default_camera_axes(), w, h), 0)
+    assert np.array_equal(od[ys, xs].view(np.uint32), dirs[ys, xs].view(np.uint32))
