@@ -65,11 +65,15 @@ typedef struct {
     uint32_t iterations_per_batch; /* samples per pixel in flight at once; 0 = auto     */
     uint32_t profile;              /* bit 0: time every launch with HIP events; bit 1:
                                       count BVH nodes / triangle tests (both slower);
-                                      bit 2: evaluate the BSDF at the surface a path's last
-                                      allowed segment ends on, as frag:884-895 does, so that
-                                      pt_stats.nan_samples also counts the non-finite samples
-                                      born there (they add zero to the image either way;
-                                      one more shade launch per batch)                  */
+                                      bit 2: produce the reference's non-finite samples one
+                                      for one, so that pt_stats.nan_samples equals what the
+                                      shader would make: the BSDF is evaluated at the surface
+                                      a path's last allowed segment ends on (frag:884-895),
+                                      and an escaping ray exactly parallel to some triangle's
+                                      plane counts as the hit at t = inf it is there
+                                      (frag:404-411).  Such samples add zero to the image
+                                      either way; the check costs a scan over all triangles
+                                      per escaping ray                                   */
     uint32_t emulate_rgba8;        /* 1: beside the float sum, keep the reference's own
                                       accumulator: an 8-bit RGBA texel per pixel updated as
                                       (accum*it + sample)/(it+1) and re-quantised every
@@ -206,6 +210,10 @@ int pt_read_rgba8(pt_renderer *r, uint8_t *rgba_host);
 /* Primary-ray hit codes of iteration `iteration` for every pixel. t_host and
  * dirs_host (3 floats per pixel) may be NULL. Does not touch the accumulation. */
 int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids_host, float *t_host, float *dirs_host);
+/* Intersection::normal of the same primary hits (frag:434-460), 3 floats per pixel: the corner normals
+ * weighted by the barycentric coordinates of the hit point, not renormalised (frag:450); on a light the
+ * light's transform * (0,0,1,0); zero on a miss. */
+int pt_read_hit_normals(pt_renderer *r, uint32_t iteration, float *normals_host);
 /* Closest hit of n caller-supplied rays (origins/dirs: 3 floats each, host
  * memory) through the same extend kernel the renderer uses. */
 int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float *dirs, float *t_host,

@@ -208,16 +208,77 @@ int32_t oracle_intersect(const oracle_scene *sc, const float o[3], const float d
     return hit_code(h);
 }
 
+/* The same scan for a group of rays at once: the triangles are visited in the same ascending order for
+ * every ray, each triangle's n and dot(n, v0) are evaluated once per group instead of once per ray (the
+ * same operations, hence the same bits), and the triangle data is streamed once per group.  This is what
+ * makes a scan over ten million triangles for a few thousand rays a matter of seconds. */
+#define TRACE_GROUP 32
+static void intersect_scan_group(const oracle_scene *sc, const float *light_inv, int count, const v3 *o, const v3 *d,
+                                 hit_t *h, float *t_param)
+{
+    for (int r = 0; r < count; ++r) {
+        h[r].t = INFINITY;
+        h[r].type = -1;
+        h[r].index = -1;
+    }
+    for (uint32_t i = 0; i < sc->n_triangles; ++i) {
+        const float *tri = sc->indices + 4 * (size_t)i;
+        v3 v0 = ld3(sc->vertices + 3 * (size_t)(int)tri[0]);
+        v3 v1 = ld3(sc->vertices + 3 * (size_t)(int)tri[1]);
+        v3 v2 = ld3(sc->vertices + 3 * (size_t)(int)tri[2]);
+        v3 e0 = sub3(v1, v0);
+        v3 e1 = sub3(v2, v0);
+        v3 n = normalize3(cross3(e0, e1));
+        float d0 = dot3(n, v0);
+        v3 e12 = sub3(v2, v1), e20 = sub3(v0, v2);
+        for (int r = 0; r < count; ++r) {
+            float st = (d0 - dot3(n, o[r])) / dot3(n, d[r]);
+            if (st < 0.f || st > h[r].t) continue;
+            v3 Q = V3(o[r].x + st * d[r].x, o[r].y + st * d[r].y, o[r].z + st * d[r].z);
+            if (dot3(cross3(e0, sub3(Q, v0)), n) < 0.f) continue;
+            if (dot3(cross3(e12, sub3(Q, v1)), n) < 0.f) continue;
+            if (dot3(cross3(e20, sub3(Q, v2)), n) < 0.f) continue;
+            h[r].t = st;
+            h[r].index = (int)i;
+            h[r].type = 0;
+        }
+    }
+    for (int r = 0; r < count; ++r) {
+        float tp = h[r].t;
+        for (uint32_t l = 0; l < sc->n_lights; ++l) {
+            float tl;
+            if (!rectangle_intersect(o[r], d[r], light_inv + 16 * (size_t)l, &tl)) continue;
+            if (tl < 0.f || tl > h[r].t) continue;
+            tp = tl;
+            h[r].t = 0.f; /* frag:427 */
+            h[r].index = (int)l;
+            h[r].type = 1;
+        }
+        t_param[r] = tp;
+    }
+}
+
 void oracle_trace(const oracle_scene *sc, uint64_t n, const float *origins, const float *dirs,
                   float *t_out, int32_t *id_out)
 {
     float *inv = make_light_inverses(sc);
-#pragma omp parallel for schedule(dynamic, 8)
-    for (int64_t i = 0; i < (int64_t)n; ++i) {
-        float tp;
-        hit_t h = intersect_scan(sc, inv, ld3(origins + 3 * i), ld3(dirs + 3 * i), &tp);
-        if (t_out) t_out[i] = tp;
-        if (id_out) id_out[i] = hit_code(h);
+    const int64_t groups = (int64_t)((n + TRACE_GROUP - 1) / TRACE_GROUP);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t g = 0; g < groups; ++g) {
+        v3 o[TRACE_GROUP], d[TRACE_GROUP];
+        hit_t h[TRACE_GROUP];
+        float tp[TRACE_GROUP];
+        const int64_t first = g * TRACE_GROUP;
+        const int count = (int)((int64_t)n - first < TRACE_GROUP ? (int64_t)n - first : TRACE_GROUP);
+        for (int r = 0; r < count; ++r) {
+            o[r] = ld3(origins + 3 * (first + r));
+            d[r] = ld3(dirs + 3 * (first + r));
+        }
+        intersect_scan_group(sc, inv, count, o, d, h, tp);
+        for (int r = 0; r < count; ++r) {
+            if (t_out) t_out[first + r] = tp[r];
+            if (id_out) id_out[first + r] = hit_code(h[r]);
+        }
     }
     free(inv);
 }

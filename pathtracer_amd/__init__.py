@@ -167,6 +167,7 @@ _SIGNATURES = {
     "pt_read_radiance": (C.c_int, [_vp, _f32p]),
     "pt_read_tonemapped": (C.c_int, [_vp, _u8p]),
     "pt_read_hit_ids": (C.c_int, [_vp, C.c_uint32, _i32p, _f32p, _f32p]),
+    "pt_read_hit_normals": (C.c_int, [_vp, C.c_uint32, _f32p]),
     "pt_trace_rays": (C.c_int, [_vp, C.c_uint64, _f32p, _f32p, _f32p, _i32p]),
     "pt_sample_surface": (
         C.c_int,
@@ -475,6 +476,12 @@ class Renderer:
         dirs = np.zeros((self.height, self.width, 3), np.float32) if want_dirs else None
         _check(_lib.pt_read_hit_ids(self._h, iteration, _ptr(ids, _i32p), _ptr(t, _f32p), _ptr(dirs, _f32p)))
         return ids, t, dirs
+
+    def read_hit_normals(self, iteration: int = 0) -> np.ndarray:
+        """Intersection::normal of the primary hits (frag:434-460), H x W x 3."""
+        out = np.zeros((self.height, self.width, 3), np.float32)
+        _check(_lib.pt_read_hit_normals(self._h, iteration, _ptr(out, _f32p)))
+        return out
 
     def set_exact_readbacks(self, enabled: bool) -> None:
         """False: read_hit_ids / trace_rays use the render loop's extend kernel verbatim."""

@@ -750,13 +750,8 @@ __global__ void __launch_bounds__(256) k_emit_triangles(const uint32_t *__restri
     const float cy = e0z * e1x - e0x * e1z;
     const float cz = e0x * e1y - e0y * e1x;
     const float inv_len = 1.0f / sqrtf(cx * cx + (cy * cy + cz * cz));
-    float nx = cx * inv_len, ny = cy * inv_len, nz = cz * inv_len;
-    float d0 = nx * v0[0] + (ny * v0[1] + nz * v0[2]);
-    // a zero-area triangle (NaN normal) is made inert, as the host path does: st = -1 / 0 is rejected
-    if (!(isfinite(nx) && isfinite(ny) && isfinite(nz))) {
-        nx = ny = nz = 0.f;
-        d0 = -1.f;
-    }
+    const float nx = cx * inv_len, ny = cy * inv_len, nz = cz * inv_len;
+    const float d0 = nx * v0[0] + (ny * v0[1] + nz * v0[2]);
     float4 *o = out + 4 * static_cast<size_t>(i);
     o[0] = make_float4(v0[0], v0[1], v0[2], d0);
     o[1] = make_float4(v1[0], v1[1], v1[2], nx);

@@ -124,6 +124,10 @@ void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, floa
 void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *results, int32_t *ids,
                            float *t, float *dirs, const DeviceCamera *cam);
 
+// Intersection::normal of the primary hits whose (t, code) results lie in `hits` (3 floats per pixel).
+void launch_primary_normals(hipStream_t s, LaunchShape g, uint32_t n, const SceneView &scene, PathQueue q, const float2 *hits,
+                            float *normals, const DeviceCamera &cam);
+
 void launch_pack_rays(hipStream_t s, LaunchShape g, uint32_t n, const float *origins, const float *dirs, PathQueue q,
                       uint32_t *counts_out, uint32_t region_size);
 

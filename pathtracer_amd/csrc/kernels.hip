@@ -194,13 +194,27 @@ constexpr int kIdMask = kClassBit - 1;
 // frag:393-415 with n and dot(n,v0) hoisted (same operations, same bits).
 // Among equal t the larger original index wins, which is what visiting the
 // triangles in ascending index order with "reject only if st > t" produces.
+//
+// SCAN_PREDICATE = true is the shader's acceptance test verbatim: "st < 0 || st > t" lets a NaN or
+// infinite st through (every comparison is false on them), which is how a scan over ALL triangles comes
+// to report hits at t = inf on planes the ray is parallel to, and "hits" on zero-area triangles (NaN
+// normal) by every ray.  A tree visits only the leaves whose boxes the ray meets, so it could reproduce
+// those only by accident; its leaf test (false) therefore accepts finite st >= 0 only (-0 included, as
+// the shader does), and the hits at infinity are added by the separate pass over all triangles (EXACT).
+// A zero-area triangle can then never be hit through the tree, nor by that pass (NaN == 0 is false).
+template <bool SCAN_PREDICATE>
 __device__ __forceinline__ void test_triangle(const float4 *__restrict__ tp, f3 o, f3 d, Hit &h)
 {
     const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
     const f3 v0 = mk(t0.x, t0.y, t0.z), v1 = mk(t1.x, t1.y, t1.z), v2 = mk(t2.x, t2.y, t2.z);
     const f3 n = mk(t1.w, t2.w, t3.x);
     const float st = (t0.w - dotm(n, o)) / dotm(n, d);
-    if (st < 0.f || st > h.t) return;
+    if (SCAN_PREDICATE) {
+        if (st < 0.f || st > h.t) return;
+    } else {
+        // v_cmp_class: -0, +0, positive denormal, positive normal
+        if (!__builtin_amdgcn_class(st, 0x1E0) || st > h.t) return;
+    }
     const f3 Q = mk(o.x + st * d.x, o.y + st * d.y, o.z + st * d.z);
     if (dotm(crossm(v1 - v0, Q - v0), n) < 0.f) return;
     if (dotm(crossm(v2 - v1, Q - v1), n) < 0.f) return;
@@ -287,7 +301,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
             const float4 a = q.p0[i], b = q.p1[i];
             const f3 o = mk(a.x, a.y, a.z), d = mk(a.w, b.x, b.y);
             Hit h{__builtin_inff(), -1};
-            for (uint32_t tri = 0; tri < sc.n_triangles; ++tri) test_triangle(sc.triangles + 4 * static_cast<size_t>(tri), o, d, h);
+            for (uint32_t tri = 0; tri < sc.n_triangles; ++tri) test_triangle<true>(sc.triangles + 4 * static_cast<size_t>(tri), o, d, h);
             t = h.t;
             code = h.id < 0 ? h.id : (h.id & kIdMask);
             other = h.id >= 0 && (h.id & kClassBit) != 0;
@@ -330,8 +344,12 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 // passes every comparison there (frag:405-411 are all false on inf/NaN) and is
 // reported as a hit at t = inf when nothing else is hit.  Such a hit carries
 // no radiance (every later value is NaN and the sample is dropped), so the
-// render loop treats it as the miss it geometrically is; the hit-buffer
-// readbacks run the extra pass so that they equal the reference's buffer.
+// render loop normally treats it as the miss it geometrically is; the
+// hit-buffer readbacks run the extra pass so that they equal the reference's
+// buffer, and so does a render loop that has to produce the reference's
+// non-finite samples one for one (the 8-bit accumulator emulation, the exact
+// count of such samples): the hit at infinity goes to the shade kernel like
+// any other, where everything computed from it is NaN.
 //
 // Scheduling inside a wave.  A wave owns one region of rays at a time and keeps
 // its 64 lanes fed from it: lanes whose ray has finished take the next unread
@@ -543,9 +561,9 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 const uint32_t first = code >> 3, cnt = code & 7u;
                 for (uint32_t j = 0; j < cnt; ++j) {
                     if (SCENE_LDS == 2)
-                        test_triangle(lds_tris + PT_LDS_STRIDE * static_cast<size_t>(first + j), o, d, h);
+                        test_triangle<false>(lds_tris + PT_LDS_STRIDE * static_cast<size_t>(first + j), o, d, h);
                     else
-                        test_triangle(sc.triangles + 4 * static_cast<size_t>(first + j), o, d, h);
+                        test_triangle<false>(sc.triangles + 4 * static_cast<size_t>(first + j), o, d, h);
                 }
                 if (COUNT) my_tris += cnt;
                 if (sp == 0) {
@@ -566,7 +584,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                     for (uint32_t j = 0; j < sc.n_triangles; ++j) {
                         const float4 *tp = sc.triangles + 4 * static_cast<size_t>(j);
                         const f3 nn = mk(tp[1].w, tp[2].w, tp[3].x);
-                        if (dotm(nn, d) == 0.f) test_triangle(tp, o, d, h);
+                        if (dotm(nn, d) == 0.f) test_triangle<true>(tp, o, d, h);
                     }
                 }
                 hit_t = h.t;
@@ -971,6 +989,22 @@ __device__ __forceinline__ Material load_material(const SceneView &sc, uint32_t 
     return m;
 }
 
+// frag:128-147, :434-450 on one shading record: barycentric coordinates of the hit point, then the corner
+// normals weighted by them, not renormalised.
+__device__ __forceinline__ f3 interpolated_normal(float4 s0, float4 s1, float4 s2, float4 s3, float4 s4, f3 p)
+{
+    const f3 v0 = mk(s0.x, s0.y, s0.z), v1 = mk(s1.x, s1.y, s1.z), v2 = mk(s2.x, s2.y, s2.z);
+    const f3 e0 = v1 - v0, e1 = v2 - v0, eP = p - v0;
+    const float e00 = dotm(e0, e0), e01 = dotm(e0, e1), e11 = dotm(e1, e1);
+    const float e0P = dotm(e0, eP), e1P = dotm(e1, eP);
+    const float inv = sdiv(1.f, e00 * e11 - e01 * e01);
+    const float bv = (e11 * e0P - e01 * e1P) * inv;
+    const float bw = (e00 * e1P - e01 * e0P) * inv;
+    const float bu = 1.f - bv - bw;
+    const f3 n1 = mk(s0.w, s1.w, s2.w), n2 = mk(s3.x, s3.y, s3.z), n3 = mk(s4.x, s4.y, s4.z);
+    return (n1 * bu + n2 * bv) + n3 * bw;  // frag:450
+}
+
 // One bounce for every surface hit of the hit list (frag:884-897), then wave64
 // compaction of the surviving paths into the wave's own region of the next
 // queue: one ballot + prefix rank per 64 hits, no atomics.  A path that dies
@@ -1044,16 +1078,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
                 const f3 p = mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
                 const float4 *sp = sc.shade + 5 * static_cast<size_t>(code);
                 const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
-                const f3 v0 = mk(s0.x, s0.y, s0.z), v1 = mk(s1.x, s1.y, s1.z), v2 = mk(s2.x, s2.y, s2.z);
-                const f3 e0 = v1 - v0, e1 = v2 - v0, eP = p - v0;
-                const float e00 = dotm(e0, e0), e01 = dotm(e0, e1), e11 = dotm(e1, e1);
-                const float e0P = dotm(e0, eP), e1P = dotm(e1, eP);
-                const float inv = sdiv(1.f, e00 * e11 - e01 * e01);
-                const float bv = (e11 * e0P - e01 * e1P) * inv;
-                const float bw = (e00 * e1P - e01 * e0P) * inv;
-                const float bu = 1.f - bv - bw;
-                const f3 n1 = mk(s0.w, s1.w, s2.w), n2 = mk(s3.x, s3.y, s3.z), n3 = mk(s4.x, s4.y, s4.z);
-                const f3 nrm = (n1 * bu + n2 * bv) + n3 * bw;  // not renormalised (frag:450)
+                const f3 nrm = interpolated_normal(s0, s1, s2, s3, s4, p);
 
                 const float xix = rng_next(sx, sy);
                 const float xiy = rng_next(sx, sy);
@@ -1220,6 +1245,33 @@ __global__ void __launch_bounds__(kBlock) k_unpack_primary(uint32_t n, PathQueue
             dirs[3 * at + 1] = b.x;
             dirs[3 * at + 2] = b.y;
         }
+    }
+}
+
+// Intersection::normal of the primary hits (frag:434-460): the interpolated normal on a surface, the
+// light's transform * (0,0,1,0) on a light, zero on a miss.  Slot i holds the ray of pixel pixel_of_slot(i).
+__global__ void __launch_bounds__(kBlock) k_primary_normals(uint32_t n, SceneView sc, PathQueue q,
+                                                             const float2 *__restrict__ hits, float *__restrict__ normals,
+                                                             DeviceCamera cam)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float2 h = hits[i];
+        const int code = __float_as_int(h.y);
+        f3 nrm = mk(0.f, 0.f, 0.f);
+        if (code >= 0) {
+            const float4 a = q.p0[i], b = q.p1[i];
+            const float t = h.x;
+            const f3 p = mk(a.x + a.w * t, a.y + b.x * t, a.z + b.y * t);
+            const float4 *sp = sc.shade + 5 * static_cast<size_t>(code);
+            nrm = interpolated_normal(sp[0], sp[1], sp[2], sp[3], sp[4], p);
+        } else if (code <= -2) {
+            const float *ln = sc.lights[-(code + 2)].normal;
+            nrm = mk(ln[0], ln[1], ln[2]);
+        }
+        const size_t at = pixel_of_slot(cam, i);
+        normals[3 * at + 0] = nrm.x;
+        normals[3 * at + 1] = nrm.y;
+        normals[3 * at + 2] = nrm.z;
     }
 }
 
@@ -1401,7 +1453,7 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     const bool render = out.render;
     const uint32_t primary = out.primary_of ? 1u : 0u;
     const DeviceCamera primary_cam = out.primary_of ? *out.primary_of : DeviceCamera{};
-    const bool exact_parallel = out.exact_parallel && !render;
+    const bool exact_parallel = out.exact_parallel;
     const uint32_t last = out.last_segment ? 1u : 0u;
     if (!use_bvh) {
         if (render)
@@ -1434,7 +1486,11 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     } while (0)
 #define PT_LAUNCH_EXTEND1(L)                                                                                       \
     do {                                                                                                          \
-        if (exact_parallel)                                                                                       \
+        if (exact_parallel && render && use_lt)                                                                   \
+            PT_LAUNCH_EXTEND2(false, true, L, true, true);                                                        \
+        else if (exact_parallel && render)                                                                        \
+            PT_LAUNCH_EXTEND2(false, true, L, true, false);                                                       \
+        else if (exact_parallel)                                                                                  \
             PT_LAUNCH_EXTEND2(false, true, L, false, false);                                                      \
         else if (!render)                                                                                         \
             PT_LAUNCH_EXTEND2(false, false, L, false, false);                                                     \
@@ -1484,6 +1540,12 @@ void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q
 {
     hipLaunchKernelGGL(k_unpack_primary, dim3(g.blocks), dim3(kBlock), 0, s, n, q, hits, ids, t, dirs,
                        cam ? *cam : DeviceCamera{}, cam ? 0u : 1u);
+}
+
+void launch_primary_normals(hipStream_t s, LaunchShape g, uint32_t n, const SceneView &scene, PathQueue q, const float2 *hits,
+                            float *normals, const DeviceCamera &cam)
+{
+    hipLaunchKernelGGL(k_primary_normals, dim3(g.blocks), dim3(kBlock), 0, s, n, scene, q, hits, normals, cam);
 }
 
 void launch_pack_rays(hipStream_t s, LaunchShape g, uint32_t n, const float *origins, const float *dirs, PathQueue q,

@@ -458,17 +458,21 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
         Timed t(r, 0, st);
         pt::launch_raygen(st, g, r->view, r->cam, it_first, r->world, kb, q[0], d_counts, r->region_size);
     }
+    // The reference's non-finite samples one for one (the 8-bit emulation needs them, profile bit 2 asks for
+    // them): rays that escape are checked for planes they are exactly parallel to (a "hit" at t = inf in the
+    // reference, a NaN sample), and the BSDF is evaluated at the last surface too.
+    const bool exact_samples = r->cfg.emulate_rgba8 || (r->cfg.profile & 4u);
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = q[b & 1], &out = q[(b + 1) & 1];
         // The last surface hit needs no new direction -- except that the reference still evaluates the BSDF
         // there, and a NaN it produces becomes the path's sample: the 8-bit emulation runs that last shade too,
         // and so does a renderer asked to count non-finite samples exactly (profile bit 2).
-        const bool final_shade = (b + 1 == depth) && (r->cfg.emulate_rgba8 || (r->cfg.profile & 4u));
+        const bool final_shade = (b + 1 == depth) && exact_samples;
         const bool last = (b + 1 == depth) && !final_shade;
         const int hit_row = static_cast<int>(depth + 1 + b);
         {
             Timed t(r, 1, st);
-            pt::ExtendOutput eo{true, d_hits, d_samples, true, last, false, tag, b == 0 ? &r->cam : nullptr};
+            pt::ExtendOutput eo{true, d_hits, d_samples, true, last, exact_samples, tag, b == 0 ? &r->cam : nullptr};
             pt::launch_extend(st, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, hit_row, d_counts), in,
                               eo, tc, r->n_nodes, r->scene_in_lds);
         }
@@ -704,15 +708,6 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
             }
             if (!diffuse) tri.original |= pt::kHitClassBit;
         }
-        // A zero-area triangle has a NaN normal.  The reference's scan "hits" it with every ray (frag:402-413
-        // compare false on NaN); a tree cannot, so under use_bvh such a triangle is made inert: st = -1 / 0 =
-        // -inf is rejected by the first comparison.  (The device builder does the same.)  Scan mode keeps the NaN.
-        if (r->cfg.use_bvh)
-            for (pt::BvhTriangle &tri : bvh.triangles)
-                if (!(std::isfinite(tri.nx) && std::isfinite(tri.ny) && std::isfinite(tri.nz))) {
-                    tri.nx = tri.ny = tri.nz = 0.f;
-                    tri.d0 = -1.f;
-                }
         if ((rc = upload(&r->d_tris, bvh.triangles.data(), bvh.triangles.size() * sizeof(pt::BvhTriangle)))) return rc;
     }
     if (!device_build && (rc = upload(&r->d_shade, shade.data(), shade.size() * sizeof(pt::ShadeTriangle)))) return rc;
@@ -1256,20 +1251,25 @@ int pt_read_tonemapped(pt_renderer *r, uint8_t *rgb)
     return PT_OK;
 }
 
-int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, float *dirs)
+}  // extern "C"
+
+namespace {
+// Primary rays of one iteration through the extend kernel, then any of: hit codes, distances, ray directions,
+// surface normals, per pixel.
+int read_primary(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, float *dirs, float *normals)
 {
-    PT_REQUIRE(r && (ids || t || dirs), "pt_read_hit_ids: null argument");
     PT_USABLE(r);
     PT_HIP(hipSetDevice(r->device));
     PT_HIP(sync_streams(r));
     const size_t n = static_cast<size_t>(r->width) * r->height;
     int32_t *d_ids = nullptr;
-    float *d_t = nullptr, *d_dirs = nullptr;
+    float *d_t = nullptr, *d_dirs = nullptr, *d_normals = nullptr;
     hipError_t e = hipSuccess;
     auto cleanup = [&]() {
         if (d_ids) (void)hipFree(d_ids);
         if (d_t) (void)hipFree(d_t);
         if (d_dirs) (void)hipFree(d_dirs);
+        if (d_normals) (void)hipFree(d_normals);
     };
 #define PT_TRY(expr)                \
     do {                            \
@@ -1282,6 +1282,7 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
     if (ids) PT_TRY(hipMalloc(&d_ids, n * sizeof(int32_t)));
     if (t) PT_TRY(hipMalloc(&d_t, n * sizeof(float)));
     if (dirs) PT_TRY(hipMalloc(&d_dirs, 3 * n * sizeof(float)));
+    if (normals) PT_TRY(hipMalloc(&d_normals, 3 * n * sizeof(float)));
     const pt::LaunchShape g = shape_for(r, n);
     pt::launch_raygen(r->stream, g, r->view, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_size);
     pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0],
@@ -1289,13 +1290,32 @@ int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, 
                       pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
     pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(n), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids, d_t,
                               d_dirs, &r->cam);
+    if (normals)
+        pt::launch_primary_normals(r->stream, g, static_cast<uint32_t>(n), r->view, r->q[0],
+                                   reinterpret_cast<const float2 *>(r->d_hits), d_normals, r->cam);
     PT_TRY(hipGetLastError());
+    if (normals) PT_TRY(hipMemcpyAsync(normals, d_normals, 3 * n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
     if (ids) PT_TRY(hipMemcpyAsync(ids, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
     if (t) PT_TRY(hipMemcpyAsync(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
     if (dirs) PT_TRY(hipMemcpyAsync(dirs, d_dirs, 3 * n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
     PT_TRY(sync_streams(r));
     cleanup();
     return PT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, float *dirs)
+{
+    PT_REQUIRE(r && (ids || t || dirs), "pt_read_hit_ids: null argument");
+    return read_primary(r, iteration, ids, t, dirs, nullptr);
+}
+
+int pt_read_hit_normals(pt_renderer *r, uint32_t iteration, float *normals)
+{
+    PT_REQUIRE(r && normals, "pt_read_hit_normals: null argument");
+    return read_primary(r, iteration, nullptr, nullptr, nullptr, normals);
 }
 
 int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float *dirs, float *t, int32_t *ids)

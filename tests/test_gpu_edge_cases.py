@@ -1,0 +1,136 @@
+"""Non-finite samples, zero-area triangles and failed resizes on a real MI355X, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import default_camera_axes, hit_fixture, scene_arrays
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(pt, name):
+    return pt.Scene.from_arrays(**scene_arrays(name))
+
+
+# ------------------------------------------------------------------ non-finite samples
+
+@pytest.mark.parametrize("name,w,h,spp", [("Box", 256, 256, 256), ("Veggie", 128, 128, 256)])
+def test_non_finite_samples_are_counted_like_the_reference_makes_them(pt, ob, name, w, h, spp):
+    """The reference never ends a path because its throughput went NaN or inf: the sample is
+    attenuation * intensity (frag:901) wherever the path ends, unless a later pdf <= 0 zeroes it
+    (frag:890-894); and a ray that escapes exactly parallel to some triangle's plane is a hit at t = inf
+    there (frag:404-411), hence a NaN sample -- most of the reference's non-finite samples are of that
+    kind (the RNG returns exact zeros, which make exactly axis-parallel bounce directions).  With profile
+    bit 2 the count of non-finite samples must equal the oracle's within 2 % (the paths are the same ones:
+    the RNG is integer-exact; the few that differ are those a last-bit difference of sin / cos sends
+    elsewhere).  Without it the render loop skips what only serves that count; the image is the same."""
+    depth = 8
+    r = pt.Renderer(_scene(pt, name), pt.Camera(resolution=(w, h)), max_depth=depth, profile=4)
+    r.draw(spp)
+    s = r.read_sum()
+    st = r.stats()
+    r.close()
+    osum, ost = ob.render(ob.OracleScene(scene_arrays(name)), ob.make_camera(*default_camera_axes(), w, h), 0, spp, depth,
+                          min(16, os.cpu_count() or 1))
+    print(f"{name}: non-finite samples {st['nan_samples']} (oracle {ost['nan_samples']}) of {st['paths']} paths")
+    assert ost["nan_samples"] > 20
+    assert abs(st["nan_samples"] - ost["nan_samples"]) <= max(2, 0.02 * ost["nan_samples"])
+    assert np.isfinite(s).all() and np.all(s[..., 3] == spp)
+    # without the bit: no BSDF at the last surface, no parallel-plane check: the count can only be lower
+    r = pt.Renderer(_scene(pt, name), pt.Camera(resolution=(w, h)), max_depth=depth)
+    r.draw(spp)
+    s0 = r.read_sum()
+    st0 = r.stats()
+    r.close()
+    assert np.array_equal(s0, s)
+    assert st0["nan_samples"] <= st["nan_samples"]
+
+
+def test_rgba8_running_average_with_non_finite_channels(pt, ob):
+    """Veggie's black rough material makes throughputs with inf and NaN channels (0 * inf).  The 8-bit
+    accumulator sees them channel by channel (NaN stores 0, +inf stores 255): against the oracle's
+    emulation on a small frame, >= 99.5 % of the texels identical, none further than 2."""
+    a = scene_arrays("Veggie")
+    w, h, n = 64, 48, 24
+    acc = ob.render_rgba8(ob.OracleScene(a), ob.make_camera(*default_camera_axes(), w, h), 0, n, 10,
+                          nthreads=min(16, os.cpu_count() or 1))
+    r = pt.Renderer(pt.Scene.from_arrays(**a), pt.Camera(resolution=(w, h)), max_depth=10, emulate_rgba8=True,
+                    iterations_per_batch=7)
+    r.draw(n)
+    tex = r.read_rgba8()
+    r.close()
+    d = np.abs(tex.astype(int) - acc.astype(int))
+    assert (d == 0).mean() >= 0.995 and d.max() <= 2, ((d == 0).mean(), d.max())
+
+
+# ------------------------------------------------------------------ zero-area triangles
+
+def test_zero_area_triangle_is_inert_in_the_tree_and_the_reference_s_in_scan_mode(pt, ob):
+    """A zero-area triangle has a NaN normal.  The reference's scan accepts it for every ray and loses its
+    closest-hit ordering after it (frag:402-413 compare false on NaN): use_bvh = 0 reproduces that, checked
+    against the oracle.  Under the tree such a triangle can never be hit: the hit buffer is the one of the
+    scene without it, through both builders."""
+    a = dict(scene_arrays("Box"))
+    nv, nt = a["vertices"].shape[0], a["indices"].shape[0]
+    p = np.array([[0.1, 0.2, 0.3], [0.6, -0.3, 0.9]], np.float32)
+    a["vertices"] = np.concatenate([a["vertices"], p])
+    a["indices"] = np.concatenate([a["indices"], np.array([[nv, nv + 1, nv + 1, nt]], np.float32)])  # two corners coincide
+    a["vertex_data"] = np.concatenate([a["vertex_data"], np.tile(np.array([[0, 0, -1, 0, 0, 0]], np.float32), (3, 1))])
+    a["material_map"] = np.concatenate([a["material_map"], np.array([0], np.uint32)])
+    fx = hit_fixture("Box")["ids"]
+    for builder in ("host", "device"):
+        r = pt.Renderer(pt.Scene.from_arrays(**a), pt.Camera(resolution=(256, 256)), bvh_builder=builder)
+        ids, _, _ = r.read_hit_ids(0)
+        r.draw(4)
+        s = r.read_sum()
+        r.close()
+        assert np.array_equal(ids, fx)
+        assert np.isfinite(s).all() and s[..., :3].max() > 0
+    oid, _, _ = ob.primary(ob.OracleScene(a), ob.make_camera(*default_camera_axes(), 256, 256), 0)
+    r = pt.Renderer(pt.Scene.from_arrays(**a), pt.Camera(resolution=(256, 256)), use_bvh=False)
+    ids, _, _ = r.read_hit_ids(0)
+    r.close()
+    assert np.array_equal(ids, oid)
+    assert (oid == nt).sum() > 10_000  # the reference "hits" it wherever nothing after it in scan order is hit
+
+
+# ------------------------------------------------------------------ failed resizes
+
+def test_resize_that_fails_leaves_a_working_renderer(pt):
+    """An image with more pixels than 32-bit path slots is refused before anything is freed; one that does
+    not fit in device memory is refused after the old buffers are gone, and the previous size is restored
+    with the accumulation reset.  Either way the renderer keeps rendering (or says PT_ERR_STATE)."""
+    r = pt.Renderer(_scene(pt, "Box"), pt.Camera(resolution=(96, 64)), max_depth=5)
+    r.draw(3)
+    before = r.read_sum()
+    with pytest.raises(pt.PtError, match="too large"):
+        r.resize(70000, 70000)
+    r.width, r.height = 96, 64
+    assert np.array_equal(r.read_sum(), before)  # nothing was touched
+    # 46000^2 pixels: ~320 GB of path buffers, more than an MI355X holds
+    failed = False
+    try:
+        r.resize(46000, 46000)
+    except pt.PtError as e:
+        failed = True
+        msg = str(e)
+    if not failed:
+        r.close()
+        pytest.skip("this GPU has room for a 46000 x 46000 frame")
+    r.width, r.height = 96, 64
+    if "previous size was restored" in msg:
+        s = r.read_sum()
+        assert s.shape == before.shape and not s.any()  # accumulation reset
+        r.draw(3)
+        assert np.array_equal(r.read_sum(), before)
+    else:
+        assert "no image buffers" in msg
+        with pytest.raises(pt.PtError, match="pt_resize"):
+            r.draw(1)
+        with pytest.raises(pt.PtError, match="pt_resize"):
+            r.read_sum()
+        r.resize(96, 64)
+        r.draw(3)
+        assert np.array_equal(r.read_sum(), before)
+    r.close()

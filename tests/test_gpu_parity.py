@@ -94,6 +94,21 @@ def test_primary_other_iteration_and_aspect(pt, w, h, it):
     assert np.array_equal(t.view(np.uint32)[geo], fx["t_bits"][geo])
 
 
+@pytest.mark.parametrize("name,w,h,it", [("Box", 256, 256, 0), ("Veggie", 256, 256, 0), ("Box_Transmission", 256, 256, 0),
+                                         ("Box_Anisotropic", 256, 256, 0), ("Box", 256, 256, 7), ("Box", 192, 108, 3)])
+def test_primary_hit_normals_bit_exact_vs_reference(pt, name, w, h, it):
+    """Intersection::normal as the reference's own intersect() leaves it (frag:434-460; fixture: a debug
+    main() writing vec4(t, normal)): interpolated and not renormalised on surfaces, the light's normal
+    on the light, zero where nothing is hit -- bit for bit on every pixel."""
+    fx = hit_fixture(name, w, h, it)
+    r = _renderer(pt, name, w, h)
+    nrm = r.read_hit_normals(it)
+    r.close()
+    bad = (nrm.view(np.uint32) != fx["normal_bits"]).any(axis=2)
+    assert not bad.any(), f"{int(bad.sum())} normals differ"
+    assert (fx["ids"] <= -2).any() and np.abs(nrm[fx["ids"] <= -2]).max() > 0.9  # light pixels carry the light's normal
+
+
 def test_primary_matches_oracle_at_odd_sizes(pt, ob):
     """Ragged sizes (not multiples of the wave or block size) and 1x1."""
     for name, w, h, it in [("Box", 1, 1, 0), ("Box", 63, 5, 2), ("Veggie", 257, 3, 9), ("TEST", 130, 70, 1)]:

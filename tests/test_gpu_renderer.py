@@ -2,6 +2,8 @@
 accumulation, reset / resize / camera changes, batch independence,
 determinism, the sample-space partition used for multi-GPU runs, and
 size-independent properties at the benchmark's full size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -111,6 +113,31 @@ def test_mean_and_tonemap_readbacks(pt, ob):
     assert tm.max() > 100  # the light is visible
 
 
+def test_tonemapped_readback_against_what_the_reference_s_post_pass_drew(pt, tmp_path):
+    """post.frag.glsl:9-18 as llvmpipe ran it on a 64-spp float image of Box.obj (fixture: that image and
+    the RGBA8 texels the post pass drew from it).  The float image is put into the renderer through a
+    checkpoint file (header written by the renderer itself, payload replaced: sum = the image, count = 1);
+    pt_read_tonemapped must then give the reference's texels to within one step of 255 (pow differs in
+    the last bits), and nearly all of them exactly."""
+    from conftest import LLVMPIPE
+    fx = np.load(os.path.join(LLVMPIPE, "post_Box_256x256_spp64_depth8.npz"))
+    r = _renderer(pt, "Box", 256, 256, max_depth=8)
+    path = str(tmp_path / "state.bin")
+    r.save_state(path)
+    raw = bytearray(open(path, "rb").read())
+    payload = np.concatenate([fx["mean_rgb"].astype(np.float32), np.ones((256, 256, 1), np.float32)], axis=2)
+    assert len(raw) > payload.nbytes
+    raw[len(raw) - payload.nbytes:] = payload.tobytes()
+    open(path, "wb").write(bytes(raw))
+    r.load_state(path)
+    assert np.array_equal(r.read_radiance()[..., :3], fx["mean_rgb"])
+    out = r.read_tonemapped()
+    r.close()
+    ref = fx["post_rgba8"][::-1, :, :3]  # the texture's row 0 is the bottom row, the readback's the top row
+    d = np.abs(out.astype(int) - ref.astype(int))
+    assert d.max() <= 1 and (d == 0).mean() > 0.999, (d.max(), (d == 0).mean())
+
+
 def test_partition_union_equals_single_renderer(pt):
     """Rank g of G renders iterations g, g+G, ...: the union is the single-GPU
     sample set, so the summed buffers agree up to fp32 addition order."""
@@ -213,6 +240,7 @@ def test_checkpoint_and_resume(pt, tmp_path):
     straight = _renderer(pt, "Box", 96, 64, max_depth=6)
     straight.draw(12)
     ref = straight.read_sum()
+    ref_stats = straight.stats()
     straight.close()
 
     a = _renderer(pt, "Box", 96, 64, max_depth=6)
@@ -226,6 +254,9 @@ def test_checkpoint_and_resume(pt, tmp_path):
     b.draw(7)
     assert np.array_equal(b.read_sum(), ref)
     assert b.stats()["iterations"] == 12 and b.stats()["paths"] == 12 * 96 * 64
+    # the counters behind the statistics travel with the file: they cover the whole render, like `paths`
+    for key in ("segments", "nan_samples", "hits_shaded"):
+        assert b.stats()[key] == ref_stats[key], key
     b.close()
 
     # partitioned renderers keep their own files
