@@ -204,6 +204,13 @@ int pt_read_radiance(pt_renderer *r, float *rgba_host);
 /* post.frag:11-15 (Reinhard then gamma 1/2.2) on the mean, as 8-bit RGB,
  * row 0 = TOP row (image-file order). */
 int pt_read_tonemapped(pt_renderer *r, uint8_t *rgb_host);
+/* pt_read_tonemapped for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * preview loops, harnesses that forbid hipMalloc): the same kernel, the same bytes, but the 8-bit image is
+ * staged in a device array that is part of the library (one copy per GPU, 10.5 MiB, held until the process
+ * ends) instead of a buffer allocated and freed per call.  No counterpart in the reference.  Images of more
+ * than 2560 x 1440 = 3 686 400 pixels are refused with PT_ERR_INVALID.  All calls on one GPU share that
+ * GPU's array: calls that overlap in time on the same GPU (two renderers driven from two threads) race. */
+int pt_read_tonemapped_noalloc(pt_renderer *r, uint8_t *rgb_host);
 /* The emulated 8-bit accumulation texture (pt_config.emulate_rgba8): width*height*4 bytes, row 0 = bottom
  * row like the texture the reference's shader reads back (frag:900), before post.frag. */
 int pt_read_rgba8(pt_renderer *r, uint8_t *rgba_host);

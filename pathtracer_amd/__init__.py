@@ -166,6 +166,7 @@ _SIGNATURES = {
     "pt_read_sum": (C.c_int, [_vp, _f32p]),
     "pt_read_radiance": (C.c_int, [_vp, _f32p]),
     "pt_read_tonemapped": (C.c_int, [_vp, _u8p]),
+    "pt_read_tonemapped_noalloc": (C.c_int, [_vp, _u8p]),
     "pt_read_hit_ids": (C.c_int, [_vp, C.c_uint32, _i32p, _f32p, _f32p]),
     "pt_read_hit_normals": (C.c_int, [_vp, C.c_uint32, _f32p]),
     "pt_trace_rays": (C.c_int, [_vp, C.c_uint64, _f32p, _f32p, _f32p, _i32p]),
@@ -468,6 +469,12 @@ class Renderer:
     def read_tonemapped(self) -> np.ndarray:
         out = np.zeros((self.height, self.width, 3), np.uint8)
         _check(_lib.pt_read_tonemapped(self._h, _ptr(out, _u8p)))
+        return out
+
+    def read_tonemapped_noalloc(self) -> np.ndarray:
+        """read_tonemapped through the library's own staging array: no device allocation in the call."""
+        out = np.zeros((self.height, self.width, 3), np.uint8)
+        _check(_lib.pt_read_tonemapped_noalloc(self._h, _ptr(out, _u8p)))
         return out
 
     def read_hit_ids(self, iteration: int = 0, want_t: bool = False, want_dirs: bool = False):

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -26,6 +27,32 @@
 namespace {
 
 thread_local std::string g_last_error;
+
+// Staging memory of pt_read_tonemapped_noalloc: the 8-bit RGB image the tone-map kernel writes before it is
+// copied to the caller.  A file-scope device array instead of a hipMalloc per call, for callers that must not
+// allocate.  Every GPU the library runs on holds its own copy of the array, at its own address, until the
+// process ends; in host code the name below is only a handle for hipGetSymbolAddress, never a device address.
+constexpr size_t kNoAllocMaxPixels = size_t(2560) * 1440;
+constexpr size_t kNoAllocScratchBytes = 3 * kNoAllocMaxPixels;  // 10.5 MiB per GPU
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU, set by scratch_init
+
+// Looks up the address of `scratch` on `device`, which must be the current device; once per device.
+hipError_t scratch_init(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+    return hipSuccess;
+}
 
 int fail(int code, const std::string &msg)
 {
@@ -951,6 +978,7 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     if (device < 0) PT_HIP(hipGetDevice(&device));
     if (device >= ndev) return fail(PT_ERR_INVALID, "pt_create: device ordinal out of range");
     PT_HIP(hipSetDevice(device));
+    PT_HIP(scratch_init(device));  // the device is current: address of the no-alloc staging array on this GPU
 
     pt_renderer *r = new pt_renderer();
     r->cfg = cfg;
@@ -1203,6 +1231,27 @@ int pt_read_sum(pt_renderer *r, float *rgba)
     PT_HIP(sync_streams(r));  // batches of both streams add to the sum
     PT_HIP(hipMemcpyAsync(rgba, r->d_sum, static_cast<size_t>(r->width) * r->height * sizeof(float4), hipMemcpyDeviceToHost,
                           r->stream));
+    PT_HIP(sync_streams(r));
+    return PT_OK;
+}
+
+int pt_read_tonemapped_noalloc(pt_renderer *r, uint8_t *rgb)
+{
+    PT_REQUIRE(r && rgb, "pt_read_tonemapped_noalloc: null argument");
+    PT_USABLE(r);
+    const size_t n = static_cast<size_t>(r->width) * r->height;
+    if (n > kNoAllocMaxPixels)
+        return fail(PT_ERR_INVALID, "pt_read_tonemapped_noalloc: " + std::to_string(r->width) + " x " + std::to_string(r->height) +
+                                        " pixels exceed the staging array (" + std::to_string(kNoAllocMaxPixels) +
+                                        " pixels, e.g. 2560 x 1440); use pt_read_tonemapped");
+    PT_HIP(hipSetDevice(r->device));
+    unsigned char *staging = (r->device >= 0 && r->device < kMaxDevices) ? g_scratch_ptr[r->device] : nullptr;
+    if (!staging) return fail(PT_ERR_STATE, "pt_read_tonemapped_noalloc: no staging array on this device");
+    PT_HIP(sync_streams(r));
+    // the kernel writes all 3 * n bytes the copy reads: nothing of an earlier call's contents is seen
+    pt::launch_tonemap(r->stream, shape_for(r, n), r->d_sum, staging, r->width, r->height);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipMemcpyAsync(rgb, staging, 3 * n, hipMemcpyDeviceToHost, r->stream));
     PT_HIP(sync_streams(r));
     return PT_OK;
 }
