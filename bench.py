@@ -3,12 +3,14 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the wavefront integrator over one batch of synthetic
-work: `--spp-per-step` (32) iterations (samples per pixel) of the scene at
-1920x1080, max depth 8, on every rank (weak scaling: rank g of G renders
-iterations g, g+G, ...).  The per-GPU radiance sums are combined by one
-reduce (RCCL when G > 1) at the end of the timed region.  Rank 0 prints ONE
-JSON line; `value` is whole-job Mpaths/s.
+A step is one 256-spp render (`--spp-per-step`; the sample count of the
+benchmark configurations) of the scene at 1920x1080, max depth 8, on every rank,
+issued as batches of 32 samples per pixel (weak scaling: rank g of G renders
+iterations g, g+G, ...).  With `--total-spp N` a step is instead one render of N
+samples per pixel IN TOTAL, split over the ranks (strong scaling: the 4K
+configurations with 1024 / 4096 spp).  The per-GPU radiance sums are combined
+by one RCCL reduce (the library's own, `pt_reduce_sum`) at the end of the timed
+region.  Rank 0 prints ONE JSON line; `value` is whole-job Mpaths/s.
 
 The renderer keeps two batches in flight (two sets of path buffers, two HIP
 streams), so the launches of consecutive steps overlap on the GPU.
@@ -34,6 +36,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (spec)
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (spec, FMA = 2 flops)
+# VALU lane-operations per second the chip can issue: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 
 # Algorithmic HBM bytes per work item with the queue records this build uses
 # (three 16-byte lanes of path state, a 16-byte hit record, a 16-byte sample):
@@ -54,7 +58,12 @@ def parse_args():
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--depth", type=int, default=8)
-    p.add_argument("--spp-per-step", type=int, default=32)
+    p.add_argument("--spp-per-step", type=int, default=256,
+                   help="samples per pixel one step renders on every rank (weak scaling)")
+    p.add_argument("--batch-spp", type=int, default=32, help="samples per pixel in flight together (pt_config.iterations_per_batch)")
+    p.add_argument("--total-spp", type=int, default=0,
+                   help="strong scaling: a step is one render of this many samples per pixel in total, rank g of G "
+                        "rendering iterations g, g+G, ... of them")
     p.add_argument("--lattice", type=int, default=0,
                    help="instance the scene's shapes (all but its 10 room triangles) on an N^3 lattice")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -73,44 +82,64 @@ def load_scene(pt, name):
     return scene.instance_lattice(10, LATTICE) if LATTICE else scene
 
 
-def timed_run(pt, torch, dist, args, scene_name, rank, world, device, distributed):
-    """Returns (seconds for K steps [max over ranks], renderer)."""
-    cam = pt.Camera(resolution=(args.width, args.height))
-    r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
-                    iterations_per_batch=args.spp_per_step)
-    r.set_partition(rank, world)
-    for _ in range(args.warmup):
-        r.draw(args.spp_per_step)
-    r.synchronize()
-    if distributed:
-        # the collective of the timed region once before it (communicator set-up, kernel load)
+def spp_of_step(args, rank, world):
+    """Samples per pixel THIS rank renders in one step."""
+    if args.total_spp:
+        return max(0, (args.total_spp - rank + world - 1) // world)  # iterations rank, rank + world, ... < total
+    return args.spp_per_step
+
+
+class Reducer:
+    """The one reduce at the end of a render.  The library's own RCCL path (pt_comm_*, pt_reduce_sum: ncclReduce
+    on the renderer's stream); torch.distributed only carries the communicator id to the ranks."""
+
+    def __init__(self, pt, dist, rank, world, device):
         from pathtracer_amd import distributed as ptd
 
-        ptd.reduce_sum_to_root(ptd.sum_buffer_as_tensor(r, f"cuda:{device}"), 0)
-        torch.cuda.synchronize()
+        self.pt, self.kind = pt, "rccl (pt_reduce_sum)"
+        self.comm = ptd.native_comm(rank, world, device)
+
+    def __call__(self, r):
+        self.pt.reduce_sum([r], [self.comm], 0)
+
+    def close(self):
+        self.comm.close()
+
+
+def timed_run(pt, dist, args, scene_name, rank, world, device, reducer):
+    """Returns (seconds for K steps [max over ranks], renderer, samples per pixel the root holds per step)."""
+    cam = pt.Camera(resolution=(args.width, args.height))
+    r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
+                    iterations_per_batch=args.batch_spp)
+    r.set_partition(rank, world)
+    spp = spp_of_step(args, rank, world)
+    for _ in range(args.warmup):
+        r.draw(spp)
+    if reducer:
+        reducer(r)  # the collective of the timed region once before it (connection set-up, kernel load)
+    r.synchronize()
     r.reset()
     r.synchronize()
 
     def fence():
         r.synchronize()
-        if torch is not None:
-            torch.cuda.synchronize()
-        if distributed:
+        if dist is not None:
             dist.barrier()
 
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        r.draw(args.spp_per_step)
-    if distributed:
-        from pathtracer_amd import distributed as ptd
-
-        r.synchronize()
-        ptd.reduce_sum_to_root(ptd.sum_buffer_as_tensor(r, f"cuda:{device}"), 0)
+        r.draw(spp)
+        if reducer and args.total_spp:
+            reducer(r)  # strong scaling: every step is a complete render, reduce included
+    if reducer and not args.total_spp:
+        reducer(r)
     fence()
     dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}")
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, r
@@ -123,14 +152,15 @@ def kernel_profile(pt, args, scene_name, device, rank, world, batch_streams=2, c
     with the other batch; 1: every kernel alone on the GPU."""
     cam = pt.Camera(resolution=(args.width, args.height))
     r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
-                    iterations_per_batch=args.spp_per_step, profile=1, batch_streams=batch_streams)
+                    iterations_per_batch=args.batch_spp, profile=1, batch_streams=batch_streams)
     r.set_partition(rank, world)
-    r.draw(args.spp_per_step)  # warm
+    spp = max(1, spp_of_step(args, rank, world))
+    r.draw(min(spp, args.batch_spp))  # warm
     r.synchronize()
     r.reset()
-    steps = min(args.steps, 10)
+    steps = max(1, min(args.steps, 4))
     for _ in range(steps):
-        r.draw(args.spp_per_step)
+        r.draw(spp)
     st = r.stats()
     r.close()
     if not counters:
@@ -138,9 +168,9 @@ def kernel_profile(pt, args, scene_name, device, rank, world, batch_streams=2, c
     # Work counters (BVH nodes fetched, triangle tests) come from a separate
     # instrumented pass so that they do not slow the timed kernels down.
     r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
-                    iterations_per_batch=args.spp_per_step, profile=2)
+                    iterations_per_batch=args.batch_spp, profile=2)
     r.set_partition(rank, world)
-    r.draw(args.spp_per_step)
+    r.draw(min(spp, args.batch_spp))
     c = r.stats()
     r.close()
     scale = st["segments"] / max(1, c["segments"])
@@ -153,7 +183,7 @@ def kernel_profile(pt, args, scene_name, device, rank, world, batch_streams=2, c
 
 def cpu_baseline(args, scene_name):
     """The CPU oracle (plain-C restatement of the reference shader, linear
-    scan) on a bounded sample: one iteration of the same frame."""
+    scan) on a bounded sample: a few iterations of the same frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
 
@@ -167,12 +197,11 @@ def cpu_baseline(args, scene_name):
     threads = min(16, os.cpu_count() or 1)
     t0 = time.perf_counter()
     n_it = 0
-    stats = None
     while True:
-        _, stats = ob.render(sc, oc, n_it, n_it + 1, args.depth, threads)
+        ob.render(sc, oc, n_it, n_it + 1, args.depth, threads)
         n_it += 1
         el = time.perf_counter() - t0
-        if el > 10.0 or n_it >= 8:
+        if el > 12.0 or n_it >= 64:
             break
     paths = args.width * args.height * n_it
     return {"value": paths / el / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
@@ -189,43 +218,64 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        # --gpus does not start processes: one rank per GPU comes from the launcher
+        raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} ranks but WORLD_SIZE is {world}; launch it as\n"
+                         f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"--master-port 29500 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
     distributed = world > 1
-    torch = dist = None
-    if distributed or args.gpus > 1:
-        import torch
+    dist = None
+    # Rehearsal on a one-GPU box: every rank on GPU 0 (RCCL refuses two ranks on one device, so the sums are
+    # combined on the host through gloo).  Exercises the multi-rank control flow only; its numbers mean nothing.
+    rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
+    if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # Rehearsal on a one-GPU box: every rank on GPU 0 and gloo instead of RCCL (RCCL refuses two ranks on one
-        # device).  Exercises the multi-rank control flow only; its numbers mean nothing.
-        rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
+        # torch.distributed is the control plane only (communicator id, barrier, max over ranks of the time):
+        # gloo on the host; the data path is the library's own RCCL reduce.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
         if rehearsal:
             local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if distributed and rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        elif distributed:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     import pathtracer_amd as pt
 
     if pt.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     device = local_rank if distributed else 0
 
-    dt, r = timed_run(pt, torch, dist, args, args.scene, rank, world, device, distributed)
+    reducer = None
+    if distributed and rehearsal:
+        import torch
+
+        class HostReduce:  # rehearsal only
+            kind = "gloo on the host (rehearsal)"
+
+            def __call__(self, r):
+                t = torch.from_numpy(r.read_sum())
+                dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+                self.total = t.numpy()
+
+            def close(self):
+                pass
+
+        reducer = HostReduce()
+    elif distributed:
+        reducer = Reducer(pt, dist, rank, world, device)
+
+    dt, r = timed_run(pt, dist, args, args.scene, rank, world, device, reducer)
     st = r.stats()
     n_pixels = args.width * args.height
-    paths_per_rank = n_pixels * args.spp_per_step * args.steps
-    total_paths = paths_per_rank * world
+    spp_all_ranks = args.total_spp if args.total_spp else args.spp_per_step * world  # per step, whole job
+    total_paths = n_pixels * spp_all_ranks * args.steps
     value = total_paths / dt / 1e6
 
     gates = {}
     if rank == 0:
         fx = os.path.join(ROOT, "tests", "golden", "llvmpipe", f"hit_{args.scene}_{args.width}x{args.height}_it0.npz")
-        if os.path.exists(fx):
+        if os.path.exists(fx) and not LATTICE:
             ids, _, _ = r.read_hit_ids(0)
             gates["primary_hit_ids_bit_exact_vs_reference"] = bool(np.array_equal(ids, np.load(fx)["ids"]))
-        s = r.read_sum()
+        s = reducer.total if (reducer is not None and rehearsal) else r.read_sum()
         gates["samples_per_pixel_root"] = float(s[..., 3].mean())
         gates["image_finite"] = bool(np.isfinite(s).all())
     r.close()
@@ -236,7 +286,7 @@ def main():
                                                             counters=False)
     out = None
     if rank == 0:
-        seg, paths = prof["segments"], prof["paths"]
+        seg = prof["segments"]
 
         def kernel_table(p):
             shaded = p["hits_shaded"]  # surface hits handed to the shade kernel
@@ -248,7 +298,7 @@ def main():
                 "raygen": {"ms_total": p["ms_raygen"], "launches": p["launches_raygen"],
                            "algorithmic_bytes": RAYGEN_BYTES_PER_PATH * p["paths"]},
                 "accumulate": {"ms_total": p["ms_accumulate"], "launches": p["launches_accumulate"],
-                               "algorithmic_bytes": 16 * p["paths"] + 32 * n_pixels * p["launches_accumulate"]},
+                               "algorithmic_bytes": SAMPLE_BYTES * p["paths"] + 32 * n_pixels * p["launches_accumulate"]},
             }
             for k in table.values():
                 k["avg_launch_ms"] = k["ms_total"] / max(1, k["launches"])
@@ -258,11 +308,11 @@ def main():
         kernels = kernel_table(prof)
         alone = kernel_table(prof_alone) if prof_alone else None
         dom = max(("extend", "shade"), key=lambda n: kernels[n]["ms_total"])
-        achieved = kernels[dom]["achieved_GBs"]
-        # counted work for the VALU view: box tests ~ 2 x 17 flops per node, triangle test ~ 85 flops
+        hbm_achieved = kernels[dom]["achieved_GBs"]
+        # counted work for the flop view: box tests ~ 2 x 17 flops per node, triangle test ~ 85 flops
         flops = prof["nodes_visited"] * 44.0 + prof["tris_tested"] * 85.0 + seg * 60.0
-        # HBM bytes per launch and VALU figures of the same command under rocprofv3 --pmc (separate passes,
-        # FETCH_SIZE doubled for gfx950), kept with the profile summaries.
+        # Counters of the same command under rocprofv3 --pmc (separate passes, FETCH_SIZE doubled for gfx950),
+        # kept with the profile summaries: HBM bytes per launch, VALU issue utilisation, active lanes.
         pmc, traffic = {}, None
         tag = f"{args.scene}_lattice{LATTICE}" if LATTICE else args.scene
         pmc_file = os.path.join(ROOT, "profiles", f"pmc_{tag}_{args.width}x{args.height}.json")
@@ -278,34 +328,61 @@ def main():
                 traffic = pmc[dom]["hbm_read_bytes_per_launch"] + pmc[dom].get("hbm_write_bytes_per_launch", 0.0)
         occupancy = {"shade_lane_fill": prof["hits_shaded"] / max(1, 64 * prof["shade_batches"]),
                      "extend_lanes_holding_a_ray": prof["diag_lanes"]}
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        # What binds the dominant kernel.  The traversal kernel is bound by VALU issue: the figure of merit is
+        # the share of the chip's VALU lane-slots that do work = (share of issue cycles with a VALU instruction
+        # in flight, from the committed counters, rescaled to the launch duration measured here) x (active
+        # lanes per instruction / 64).  The HBM view of the same kernel is kept beside it.
+        m = pmc.get(dom, {})
+        live_alone_ms = alone[dom]["avg_launch_ms"] if alone else None
+        if "valu_issue_utilisation" in m and "active_lanes_per_valu_instruction" in m and live_alone_ms:
+            issue = m["valu_issue_utilisation"] * (m["avg_launch_us"] / 1e3) / live_alone_ms  # same instructions, today's duration
+            lanes = m["active_lanes_per_valu_instruction"]
+            bound = {"bound": "valu_issue", "achieved": issue * lanes / 64.0 * VALU_PEAK_TLANEOPS, "peak": VALU_PEAK_TLANEOPS,
+                     "unit": "T lane-ops/s", "frac": issue * lanes / 64.0,
+                     "valu_issue_utilisation": issue, "active_lanes_per_valu_instruction": lanes,
+                     "note": "kernel alone on the GPU; counters from " + os.path.relpath(pmc_file, ROOT)}
+        else:
+            bound = {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+                     "note": "no committed counter file for this workload: HBM view only"}
+        roofline = {"kernel": dom, **bound, "traffic": traffic,
+                    "hbm_achieved_GBs": hbm_achieved, "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
                     "pmc": {"source": os.path.relpath(pmc_file, ROOT) if pmc else None, **pmc},
                     "lane_occupancy": occupancy,
                     "avg_launch_ms": kernels[dom]["avg_launch_ms"],
                     "bytes_per_launch": kernels[dom]["algorithmic_bytes"] / max(1, kernels[dom]["launches"]),
                     # The timed run keeps two batches in flight on two streams, so a launch above shares the GPU
                     # with the other batch's kernels.  One batch at a time (pt_config.batch_streams = 1):
-                    "alone": {"avg_launch_ms": alone[dom]["avg_launch_ms"], "achieved": alone[dom]["achieved_GBs"],
-                              "frac": alone[dom]["achieved_GBs"] / HBM_PEAK_GBS, "kernels": alone} if alone else None,
-                    "valu_view": {"extend_counted_gflop": flops / 1e9,
+                    "alone": {"avg_launch_ms": alone[dom]["avg_launch_ms"], "hbm_achieved_GBs": alone[dom]["achieved_GBs"],
+                              "hbm_frac": alone[dom]["achieved_GBs"] / HBM_PEAK_GBS, "kernels": alone} if alone else None,
+                    "flop_view": {"extend_counted_gflop": flops / 1e9,
                                   "extend_tflops": flops / max(prof["ms_extend"], 1e-9) / 1e9,
                                   "peak_tflops": VALU_PEAK_TFLOPS,
                                   "frac": flops / max(prof["ms_extend"], 1e-9) / 1e9 / VALU_PEAK_TFLOPS},
                     "kernels": kernels}
+        # The whole pipeline against HBM: algorithmic bytes of all kernels of a step over the step's wall time.
+        bytes_per_path = sum(k["algorithmic_bytes"] for k in kernels.values()) / max(1, prof["paths"])
+        pipeline_gbs = bytes_per_path * (total_paths / world) / dt / 1e9
+        scene_label = f"{args.scene}.obj{f' instanced on a {LATTICE}^3 lattice' if LATTICE else ''}"
         out = {
             "metric": "Mpaths/sec at 1080p, 8 bounces, Box.obj & Veggie.obj; 1/2/4/8 MI355X",
             "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene}.obj{f' instanced on a {LATTICE}^3 lattice' if LATTICE else ''} "
-                                   f"{args.width}x{args.height}, max depth {args.depth}, "
-                                   f"{args.spp_per_step} spp per step per GPU, default camera and light",
-                       "paths_per_step": n_pixels * args.spp_per_step * world, "parallelism": f"sample-partition x{world}"},
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.total_spp else "weak", "vs_baseline": None,
+            "dtype": "f32",
+            "data": f"{scene_label} of the reference's assets (committed dump of its Scene arrays), the reference's default "
+                    "camera and light; samples are generated by the integrator's own RNG",
+            "config": {"workload": f"{scene_label} {args.width}x{args.height}, max depth {args.depth}, "
+                                   + (f"{args.total_spp} spp per step in total over {world} GPU(s)" if args.total_spp else
+                                      f"{args.spp_per_step} spp per step per GPU")
+                                   + f", batches of {args.batch_spp} spp, default camera and light",
+                       "paths_per_step": n_pixels * spp_all_ranks, "parallelism": f"sample-partition x{world}",
+                       "reduce": reducer.kind if reducer else None},
             "msegments_per_s": value * st["segments"] / max(1, st["paths"]),
             "segments_per_path": st["segments"] / max(1, st["paths"]),
             "gates": gates,
             "roofline": roofline,
+            "pipeline": {"algorithmic_bytes_per_path": bytes_per_path, "hbm_GBs_per_gpu": pipeline_gbs,
+                         "hbm_frac": pipeline_gbs / HBM_PEAK_GBS},
             # outside the timed region: the tree and the uploads of pt_create
             "setup": {"triangles": st["n_triangles"], "bvh_nodes": st["n_nodes"], "bvh_depth": st["bvh_depth"],
                       "bvh_builder": "device" if st["bvh_builder"] else "host", "bvh_build_ms": st["bvh_build_ms"],
@@ -314,16 +391,17 @@ def main():
         timing = os.path.join(ROOT, "tests", "golden", "llvmpipe", "llvmpipe_timing.json")
         if os.path.exists(timing):
             out["reference_llvmpipe_container"] = json.load(open(timing))
-    if rank == 0 and not args.no_extra and args.scene != "Veggie":
-        dt2, r2 = timed_run(pt, None, None, args, "Veggie", 0, 1, device, False) if not distributed else (None, None)
-        if r2 is not None:
-            st2 = r2.stats()
-            r2.close()
-            out["veggie"] = {"value": n_pixels * args.spp_per_step * args.steps / dt2 / 1e6, "unit": "Mpaths/s",
-                             "n_gpus": 1, "ms_per_step": dt2 / args.steps * 1e3,
-                             "segments_per_path": st2["segments"] / max(1, st2["paths"])}
+    if rank == 0 and not args.no_extra and args.scene != "Veggie" and not distributed:
+        dt2, r2 = timed_run(pt, None, args, "Veggie", 0, 1, device, None)
+        st2 = r2.stats()
+        r2.close()
+        out["veggie"] = {"value": n_pixels * spp_of_step(args, 0, 1) * args.steps / dt2 / 1e6, "unit": "Mpaths/s",
+                         "n_gpus": 1, "ms_per_step": dt2 / args.steps * 1e3,
+                         "segments_per_path": st2["segments"] / max(1, st2["paths"])}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, args.scene)
+    if reducer:
+        reducer.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

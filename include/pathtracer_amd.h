@@ -241,6 +241,32 @@ int pt_sample_surface(pt_renderer *r, uint64_t n, const float *materials, const 
                       const float *wo, const float *xi, const uint32_t *seeds, float *wi_out, float *pdf_out,
                       float *f_out, uint32_t *flags_out, uint32_t *seeds_out);
 
+/* ------------------------------------------------------------ Several GPUs
+ * The reference drives one GPU (one GL context, renderer.cpp:124-150).  Here the samples of a render are
+ * partitioned over GPUs (pt_set_partition: the scene is replicated, renderer g of G renders iterations g,
+ * g + G, ...; exact because a sample depends only on pixel and iteration index, frag:866) and the per-GPU
+ * sums are combined by ONE reduce over RCCL (xGMI inside a node).  No reference counterpart.
+ *
+ * A communicator is made either per process (one process per GPU: rank 0 calls pt_comm_unique_id, hands the
+ * 128 bytes to the others by any means -- a file, MPI, a torch.distributed broadcast --, and every rank
+ * calls pt_comm_create, collectively) or for all GPUs of one process at once (pt_comm_create_all). */
+#define PT_COMM_ID_BYTES 128
+typedef struct pt_comm pt_comm;
+int pt_comm_unique_id(uint8_t id[PT_COMM_ID_BYTES]);                        /* ncclGetUniqueId  */
+/* device: HIP ordinal the rank's renderer lives on; -1 = current device.       ncclCommInitRank */
+int pt_comm_create(const uint8_t id[PT_COMM_ID_BYTES], uint32_t rank, uint32_t world, int32_t device, pt_comm **out);
+/* n communicators, rank k on devices[k], written to out[0..n-1].               ncclCommInitAll  */
+int pt_comm_create_all(const int32_t *devices, uint32_t n, pt_comm **out);
+void pt_comm_destroy(pt_comm *comm);
+/* ncclReduce(sum, float) of the renderers' sum buffers (width*height*4 floats, the alpha lane carrying the
+ * sample counts) into rank `root`'s, in place, enqueued on each renderer's own stream after its pending
+ * batches: asynchronous, pt_synchronize or any readback waits for it.  n = 1 in a process that drives one
+ * GPU; a process that drives several passes all its renderers and communicators in one call (one group).
+ * Afterwards the root's pt_read_radiance is the mean over all samples of all ranks.  The other ranks' sum
+ * buffers are cleared (their samples now live in the root's buffer; iteration counters and statistics go
+ * on), so the render may continue and be reduced again, e.g. for previews.  All image sizes must agree. */
+int pt_reduce_sum(pt_renderer *const *renderers, pt_comm *const *comms, uint32_t n, uint32_t root);
+
 /* Device pointer of the sum buffer (width*height*4 floats) so that a caller
  * can reduce it across GPUs without a host round trip; valid until
  * pt_resize / pt_destroy. */

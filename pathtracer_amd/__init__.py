@@ -175,6 +175,11 @@ _SIGNATURES = {
         [_vp, C.c_uint64, _f32p, _f32p, _f32p, _f32p, _u32p, _f32p, _f32p, _f32p, _u32p, _u32p],
     ),
     "pt_set_exact_readbacks": (C.c_int, [_vp, C.c_uint32]),
+    "pt_comm_unique_id": (C.c_int, [_u8p]),
+    "pt_comm_create": (C.c_int, [_u8p, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(_vp)]),
+    "pt_comm_create_all": (C.c_int, [_i32p, C.c_uint32, C.POINTER(_vp)]),
+    "pt_comm_destroy": (None, [_vp]),
+    "pt_reduce_sum": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.c_uint32, C.c_uint32]),
     "pt_sum_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "pt_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "pt_bvh_inspect": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(BvhInfo)]),
@@ -365,6 +370,56 @@ class Camera:
     up = property(lambda self: self._get()[0][3])
     right = property(lambda self: self._get()[0][4])
     resolution = property(lambda self: tuple(int(x) for x in self._get()[1]))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """The 128 bytes rank 0 hands to the other ranks before everybody calls Comm(...)."""
+    buf = np.zeros(COMM_ID_BYTES, np.uint8)
+    _check(_lib.pt_comm_unique_id(_ptr(buf, _u8p)))
+    return buf.tobytes()
+
+
+class Comm:
+    """An RCCL communicator owned by the library (one rank of `world`, on HIP device `device`)."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int = -1, _handle=None):
+        self._h = _vp()
+        self.rank, self.world = rank, world
+        if _handle is not None:
+            self._h = _handle
+            return
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("the id is the 128 bytes comm_unique_id() returned on rank 0")
+        buf = np.frombuffer(unique_id, np.uint8).copy()
+        _check(_lib.pt_comm_create(_ptr(buf, _u8p), rank, world, device, C.byref(self._h)))
+
+    @classmethod
+    def for_devices(cls, devices) -> list:
+        """One communicator per device of this process (ncclCommInitAll)."""
+        d = np.ascontiguousarray(devices, np.int32)
+        hs = (_vp * len(d))()
+        _check(_lib.pt_comm_create_all(_ptr(d, _i32p), len(d), hs))
+        return [cls(b"", k, len(d), _handle=_vp(hs[k])) for k in range(len(d))]
+
+    def close(self) -> None:
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.pt_comm_destroy(h)
+
+    __del__ = close
+
+
+def reduce_sum(renderers, comms, root: int = 0) -> None:
+    """One RCCL reduce(sum) of the renderers' sum buffers into rank `root`'s (in place, asynchronous)."""
+    n = len(renderers)
+    if n != len(comms) or n == 0:
+        raise ValueError("one communicator per renderer")
+    rs = (_vp * n)(*[r._h for r in renderers])
+    cs = (_vp * n)(*[c._h for c in comms])
+    _check(_lib.pt_reduce_sum(rs, cs, n, root))
 
 
 class Renderer:

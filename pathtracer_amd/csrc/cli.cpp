@@ -10,6 +10,9 @@
 //             [--resume state.bin] [--save-state state.bin] [--checkpoint-every n]
 //             [--preview-every n]   rewrite --out after every n samples per pixel (a progressive preview)
 //             [--scan] [--bvh host|device] [--out image.ppm] [--pfm radiance.pfm]
+//             [--gpus n]            sample-partition the render over n GPUs of this machine: GPU g renders
+//                                   iterations g, g + n, ...; one RCCL reduce into GPU 0 before an image is
+//                                   written (not with --resume / --save-state)
 // --spp is the total: after --resume only the missing samples are rendered.
 #include <algorithm>
 #include <chrono>
@@ -56,7 +59,8 @@ int main(int argc, char **argv)
     pt::Vec3 eye = pt::make3(0.f, 1.5f, 15.f), focus = pt::make3(0.f, -0.25f, 0.f);
     bool scan = false, no_light = false, device_bvh = false;
     std::string resume, save_state;
-    uint32_t checkpoint_every = 0, preview_every = 0;
+    uint32_t checkpoint_every = 0, preview_every = 0, gpus = 1;
+    bool gpus_given = false;  // --gpus 1 takes the multi-GPU code path with a one-rank communicator
     std::vector<pt::Scene::Light> lights;
     struct Move {
         char kind;
@@ -87,6 +91,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--save-state")) save_state = next(), ++i;
         else if (!std::strcmp(argv[i], "--checkpoint-every")) checkpoint_every = std::atoi(next()), ++i;
         else if (!std::strcmp(argv[i], "--preview-every")) preview_every = std::atoi(next()), ++i;
+        else if (!std::strcmp(argv[i], "--gpus")) gpus = std::max(1, std::atoi(next())), gpus_given = true, ++i;
         else if (!std::strcmp(argv[i], "--light")) {
             float v[12];
             for (int k = 0; k < 12; ++k) v[k] = static_cast<float>(std::atof(next(k + 1)));
@@ -130,6 +135,52 @@ int main(int argc, char **argv)
             if (m.kind == 'o') camera.orbit(m.a, m.b);
             else if (m.kind == 'p') camera.pan(m.a, m.b);
             else camera.zoom(m.a);
+        }
+        if (gpus_given) {
+            // One process, several GPUs: the loop of main.cpp:183-189 over a MultiRenderer.
+            if (!resume.empty() || !save_state.empty()) {
+                std::fprintf(stderr, "--resume / --save-state do not go with --gpus\n");
+                return 2;
+            }
+            const int visible = pt_device_count();
+            if (visible < static_cast<int>(gpus)) {
+                std::fprintf(stderr, "--gpus %u, but %d GPU(s) visible\n", gpus, visible);
+                return 1;
+            }
+            pt::MultiRenderer multi(&scene, &camera, gpus, depth, fov, !scan, device_bvh);
+            auto t0 = std::chrono::steady_clock::now();
+            uint32_t done = 0;
+            while (done < spp) {
+                const uint32_t n = preview_every ? std::min(spp - done, preview_every - done % preview_every) : spp - done;
+                multi.draw(n);
+                done += n;
+                if (preview_every && done < spp) {
+                    multi.reduce();
+                    if (!write_ppm(out, multi.root().tonemapped(), width, height)) std::fprintf(stderr, "cannot write %s\n", out.c_str());
+                    std::printf("preview at %u spp\n", done);
+                }
+            }
+            multi.reduce();
+            multi.synchronize();
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            uint64_t paths = 0, segments = 0;
+            for (size_t g = 0; g < multi.gpus(); ++g) {
+                const pt_stats st = multi.renderer(g).stats();
+                paths += st.paths;
+                segments += st.segments;
+            }
+            std::printf("%zu triangles, %ux%u, %u spp on %u GPUs, depth %u: %.3f s, %.1f Mpaths/s, %.2f segments/path\n",
+                        scene.m_indices.size(), width, height, done, gpus, depth, secs, static_cast<double>(paths) / secs / 1e6,
+                        paths ? static_cast<double>(segments) / static_cast<double>(paths) : 0.0);
+            if (!write_ppm(out, multi.root().tonemapped(), width, height)) {
+                std::fprintf(stderr, "cannot write %s\n", out.c_str());
+                return 1;
+            }
+            if (!pfm.empty() && !write_pfm(pfm, multi.root().radiance(), width, height)) {
+                std::fprintf(stderr, "cannot write %s\n", pfm.c_str());
+                return 1;
+            }
+            return 0;
         }
         pt::Renderer renderer(&scene, &camera, depth, fov, !scan, -1, device_bvh);
         uint32_t done = 0;

@@ -22,6 +22,7 @@
 #include "camera.h"
 #include "device_types.h"
 #include "kernels.h"
+#include "renderer_internal.h"
 #include "scene.h"
 
 namespace {
@@ -764,6 +765,31 @@ float tan_half_fov(float degrees)
 }
 
 }  // namespace
+
+namespace pt_internal {
+
+bool sum_buffer(pt_renderer *r, SumBuffer *out)
+{
+    if (!r || !r->usable || !r->d_sum) {
+        fail(PT_ERR_STATE, "the renderer has no image buffers");
+        return false;
+    }
+    if (hipSetDevice(r->device) != hipSuccess || sync_streams(r) != hipSuccess) {
+        fail(PT_ERR_DEVICE, "synchronising the renderer's streams failed");
+        return false;
+    }
+    out->data = reinterpret_cast<float *>(r->d_sum);
+    out->count = static_cast<size_t>(r->width) * r->height * 4;
+    out->device = r->device;
+    out->stream = r->stream;
+    return true;
+}
+
+void main_stream_work_enqueued(pt_renderer *r) { mark_main_stream_work(r); }
+
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+
+}  // namespace pt_internal
 
 extern "C" {
 

@@ -100,4 +100,65 @@ private:
     }
 };
 
+// The same surface over all GPUs of one process: the scene is replicated, GPU g of G renders iterations g,
+// g + G, ... of the global sequence 0, 1, 2, ... (pt_set_partition), and reduce() combines the per-GPU sums
+// on GPU 0 with one RCCL reduce.  One host thread drives all GPUs: draw() only enqueues.
+class MultiRenderer {
+public:
+    MultiRenderer(Scene *scene, Camera *camera, uint32_t gpus, uint32_t maxDepth = 10, float fovYDegrees = 19.5f,
+                  bool useBvh = true, bool buildBvhOnDevice = false)
+    {
+        std::vector<int32_t> devices(gpus);
+        for (uint32_t g = 0; g < gpus; ++g) {
+            devices[g] = static_cast<int32_t>(g);
+            m_renderers.emplace_back(new Renderer(scene, camera, maxDepth, fovYDegrees, useBvh, static_cast<int>(g), buildBvhOnDevice));
+            check(pt_set_partition(m_renderers.back()->handle(), g, gpus));
+        }
+        m_comms.assign(gpus, nullptr);
+        check(pt_comm_create_all(devices.data(), gpus, m_comms.data()));
+    }
+    ~MultiRenderer()
+    {
+        for (pt_comm *c : m_comms) pt_comm_destroy(c);
+        for (Renderer *r : m_renderers) delete r;
+    }
+    MultiRenderer(const MultiRenderer &) = delete;
+    MultiRenderer &operator=(const MultiRenderer &) = delete;
+
+    // n more iterations of the global sequence, each on the GPU it belongs to.
+    void draw(uint32_t n = 1)
+    {
+        const uint64_t G = m_renderers.size(), after = m_done + n;
+        for (uint64_t g = 0; g < G; ++g) {
+            const uint64_t had = m_done > g ? (m_done - g + G - 1) / G : 0, want = after > g ? (after - g + G - 1) / G : 0;
+            if (want > had) m_renderers[g]->draw(static_cast<uint32_t>(want - had));
+        }
+        m_done = after;
+    }
+    // Sum of all GPUs' samples into GPU 0's renderer (asynchronous; the readbacks of root() wait for it).
+    void reduce()
+    {
+        std::vector<pt_renderer *> rs;
+        for (Renderer *r : m_renderers) rs.push_back(r->handle());
+        check(pt_reduce_sum(rs.data(), m_comms.data(), static_cast<uint32_t>(rs.size()), 0));
+    }
+    void synchronize()
+    {
+        for (Renderer *r : m_renderers) r->synchronize();
+    }
+    Renderer &root() { return *m_renderers[0]; }
+    Renderer &renderer(size_t g) { return *m_renderers[g]; }
+    size_t gpus() const { return m_renderers.size(); }
+    uint64_t iterations() const { return m_done; }
+
+private:
+    std::vector<Renderer *> m_renderers;
+    std::vector<pt_comm *> m_comms;
+    uint64_t m_done = 0;
+    static void check(int rc)
+    {
+        if (rc != PT_OK) throw std::runtime_error(std::string("pathtracer_amd: ") + pt_last_error());
+    }
+};
+
 }  // namespace pt

@@ -7,8 +7,14 @@ is that a sample depends only on (pixel, iteration index)
 (pathtracer.frag.glsl:866) and that accumulation here is a float SUM rather
 than the reference's 8-bit running average (pathtracer.frag.glsl:900-904).
 
-Load order: import torch before pathtracer_amd in such a process (torch's wheel
-brings its own HIP runtime, and the first one loaded is the one both use).
+The reduce is the library's own (`pt_reduce_sum`: ncclReduce on the renderer's
+stream); this module only bootstraps its communicator in a process group that
+already exists (`native_comm`: rank 0's 128-byte id travels through
+`torch.distributed.broadcast_object_list`, any backend -- gloo will do, torch
+never touches the GPU).  `sum_buffer_as_tensor` / `reduce_sum_to_root` are the
+older route through torch's own RCCL binding, kept for callers whose tensors
+live in torch anyway; it needs torch imported before pathtracer_amd (torch's
+wheel brings its own HIP runtime, and the first one loaded is the one both use).
 """
 from __future__ import annotations
 
@@ -24,6 +30,18 @@ def local_iterations(total_spp: int, rank: int, world: int) -> int:
 
 def iteration_indices(total_spp: int, rank: int, world: int) -> range:
     return range(rank, total_spp, world)
+
+
+def native_comm(rank: int, world: int, device: int):
+    """A library-owned RCCL communicator for this rank of an initialised torch.distributed group."""
+    import torch.distributed as dist
+
+    import pathtracer_amd as pt
+
+    box = [pt.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    return pt.Comm(box[0], rank, world, device)
 
 
 class _DeviceArray:

@@ -87,6 +87,15 @@ def test_cli_lights_camera_checkpoint_resume(tmp_path):
     assert "preview at 5 spp" in log and "preview at 10 spp" in log and "preview at 12" not in log
     assert np.array_equal(_read_pfm(tmp_path / "p.pfm"), a)
 
+    # --gpus takes the multi-GPU code path (MultiRenderer, a communicator for all GPUs of the process, one
+    # RCCL reduce before every image written); with the one GPU of a test box it must give the same image
+    log = _run(common + ["--spp", "12", "--gpus", "1", "--preview-every", "5", "--out", "g.ppm", "--pfm", "g.pfm"], tmp_path)
+    assert "on 1 GPUs" in log and "preview at 10 spp" in log
+    assert np.array_equal(_read_pfm(tmp_path / "g.pfm"), a)
+    assert (tmp_path / "a.ppm").read_bytes() == (tmp_path / "g.ppm").read_bytes()
+    many = subprocess.run([EXE, *common, "--spp", "2", "--gpus", "64"], cwd=tmp_path, capture_output=True, text=True, timeout=240)
+    assert many.returncode != 0 and "GPU(s) visible" in many.stderr
+
     dark = _run(["--scene", "room.obj", "--mtl-root", "./", "--width", "32", "--height", "32", "--spp", "2", "--no-light",
                  "--pfm", "d.pfm", "--out", "d.ppm"], tmp_path)
     assert "2 spp" in dark and not _read_pfm(tmp_path / "d.pfm").any()

@@ -18,6 +18,14 @@ def test_sum_buffer_alias_and_rccl_collective():
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-2000:] + out.stderr[-4000:]
 
 
+def test_native_rccl_reduce_in_a_world_of_one():
+    """The library's own RCCL route (pt_comm_unique_id / pt_comm_create / pt_comm_create_all / pt_reduce_sum)
+    in a process without torch."""
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "rccl_native_single_rank.py")
+    out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-2000:] + out.stderr[-4000:]
+
+
 def test_bench_two_rank_rehearsal():
     """bench.py launched the way the scaling run launches it (torch.distributed.run, one process per
     rank), with both ranks on the one GPU and gloo in place of RCCL: the sample partition, the reduce
