@@ -61,6 +61,8 @@ def parse_args():
     p.add_argument("--spp-per-step", type=int, default=256,
                    help="samples per pixel one step renders on every rank (weak scaling)")
     p.add_argument("--batch-spp", type=int, default=32, help="samples per pixel in flight together (pt_config.iterations_per_batch)")
+    p.add_argument("--batch-streams", type=int, default=2, choices=(1, 2),
+                   help="2: two batches in flight on two streams (the product default); 1: one batch at a time")
     p.add_argument("--total-spp", type=int, default=0,
                    help="strong scaling: a step is one render of this many samples per pixel in total, rank g of G "
                         "rendering iterations g, g+G, ... of them")
@@ -110,7 +112,7 @@ def timed_run(pt, dist, args, scene_name, rank, world, device, reducer):
     """Returns (seconds for K steps [max over ranks], renderer, samples per pixel the root holds per step)."""
     cam = pt.Camera(resolution=(args.width, args.height))
     r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
-                    iterations_per_batch=args.batch_spp)
+                    iterations_per_batch=args.batch_spp, batch_streams=args.batch_streams)
     r.set_partition(rank, world)
     spp = spp_of_step(args, rank, world)
     for _ in range(args.warmup):
@@ -280,7 +282,7 @@ def main():
         gates["image_finite"] = bool(np.isfinite(s).all())
     r.close()
 
-    prof = kernel_profile(pt, args, args.scene, device, rank, world)
+    prof = kernel_profile(pt, args, args.scene, device, rank, world, batch_streams=args.batch_streams)
     # the same kernels one at a time (one stream): what a launch takes when it has the GPU to itself
     prof_alone = None if args.no_alone else kernel_profile(pt, args, args.scene, device, rank, world, batch_streams=1,
                                                             counters=False)

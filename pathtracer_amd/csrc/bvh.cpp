@@ -1,4 +1,5 @@
 #include "bvh.h"
+#include "tuning.h"
 
 #include <algorithm>
 #include <atomic>
@@ -15,14 +16,14 @@ namespace {
 
 // Largest leaf.  (PT_BVH_LEAF: tuning experiments only, 1..7.)
 const uint32_t kLeafMax = [] {
-    const char *e = std::getenv("PT_BVH_LEAF");
+    const char *e = pt::tuning_env("PT_BVH_LEAF");
     const int v = e ? std::atoi(e) : 4;
     return static_cast<uint32_t>(v < 1 ? 1 : (v > 7 ? 7 : v));
 }();
 constexpr int kMaxBins = 64;
 // Cost of one inner-node step in units of one triangle test.  (PT_BVH_CT: tuning experiments only.)
 const double kTraversalCost = [] {
-    const char *e = std::getenv("PT_BVH_CT");
+    const char *e = pt::tuning_env("PT_BVH_CT");
     return e ? std::atof(e) : 1.0;
 }();
 
@@ -215,7 +216,7 @@ struct Builder {
     {
         const uint32_t n = static_cast<uint32_t>(prims.size());
         unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        if (const char *e = std::getenv("PT_BVH_THREADS")) hw = static_cast<unsigned>(std::max(1, std::atoi(e)));
+        if (const char *e = pt::tuning_env("PT_BVH_THREADS")) hw = static_cast<unsigned>(std::max(1, std::atoi(e)));
         if (n < (1u << 16) || hw < 2) return build(0, n, 0, tmp, nullptr, 0);
         std::vector<Job> jobs;
         const int32_t root = build(0, n, 0, tmp, &jobs, std::max<uint32_t>(1024, n / (8 * hw)));

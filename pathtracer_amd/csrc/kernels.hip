@@ -12,11 +12,14 @@
 //     normalize(v) = v * (1.0f / sqrtf(dot(v,v)))
 // so the primary hit buffer can be compared bit for bit.
 #include "kernels.h"
+#include "tuning.h"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 namespace pt {
 
@@ -1350,19 +1353,46 @@ namespace {
 // resident (blocks per CU from the occupancy query for this kernel and LDS
 // size), so no block waits for another to retire, and never more waves than
 // there are regions to hand out.
+// Blocks of `kernel` (block size `block`, `lds_bytes` of dynamic LDS) a CU keeps resident.  The runtime's
+// occupancy query is asked once per (kernel, LDS size) and process: it costs more than a kernel launch, and
+// the reference's usage pattern is one sample per draw (renderer.cpp:124-150), i.e. many small launches.
+int blocks_per_cu(const void *kernel, int block, size_t lds_bytes)
+{
+    struct Key {
+        const void *kernel;
+        size_t lds;
+        int block;
+        bool operator<(const Key &o) const
+        {
+            return kernel != o.kernel ? kernel < o.kernel : (lds != o.lds ? lds < o.lds : block < o.block);
+        }
+    };
+    static std::mutex mutex;
+    static std::map<Key, int> cache;
+    std::lock_guard<std::mutex> lock(mutex);
+    const Key key{kernel, lds_bytes, block};
+    const auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    cache[key] = per_cu;
+    return per_cu;
+}
+
 template <typename K>
 uint32_t resident_grid(K kernel, size_t lds_bytes, LaunchShape g, int block = kBlock, const char *cap_env = nullptr)
 {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+    int per_cu = blocks_per_cu(reinterpret_cast<const void *>(kernel), block, lds_bytes);
     if (cap_env) {  // tuning experiments only: fewer blocks per CU than fit
-        const char *e = std::getenv(cap_env);
+        const char *e = pt::tuning_env(cap_env);
         const int cap = e ? std::atoi(e) : 0;
         if (cap >= 1 && cap < per_cu) per_cu = cap;
     }
     const uint32_t resident = g.n_cus * static_cast<uint32_t>(per_cu);
     const uint32_t needed = (g.wave_items + (block / 64) - 1) / (block / 64);
-    if (std::getenv("PT_EVEN_GRID")) {  // tuning experiments only
+    if (pt::tuning_env("PT_EVEN_GRID")) {  // tuning experiments only
         const uint32_t wpb = block / 64, rw = resident * wpb, items = g.wave_items < 1 ? 1 : g.wave_items;
         const uint32_t turns = (items + rw - 1) / rw, waves = (items + turns - 1) / turns;
         return (waves + wpb - 1) / wpb;
@@ -1390,7 +1420,7 @@ struct LdsPlan {
 LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds)
 {
     static const size_t budget = [] {
-        const char *e = std::getenv("PT_LDS_BUDGET_KB");  // tuning experiments only
+        const char *e = pt::tuning_env("PT_LDS_BUDGET_KB");  // tuning experiments only
         return static_cast<size_t>(e ? std::atoi(e) : 40) * 1024;
     }();
     const size_t stack_bytes = static_cast<size_t>(stack_entries) * kExtBlock * sizeof(StackT);
@@ -1418,12 +1448,10 @@ uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t 
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds);
     const bool lt = scene.n_lights == 1u;
     int per_cu = 0;
-    hipError_t rc = hipErrorUnknown;
-#define PT_OCC(L)                                                                                                   \
-    rc = lt ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_bvh<false, false, L, true, true>,    \
-                                                           kExtBlock, plan.bytes)                                  \
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_bvh<false, false, L, true, false>,   \
-                                                           kExtBlock, plan.bytes)
+#define PT_OCC(L)                                                                                               \
+    per_cu = blocks_per_cu(lt ? reinterpret_cast<const void *>(k_extend_bvh<false, false, L, true, true>)      \
+                              : reinterpret_cast<const void *>(k_extend_bvh<false, false, L, true, false>),    \
+                           kExtBlock, plan.bytes)
     if (plan.mode == 2)
         PT_OCC(2);
     else if (plan.mode == 3)
@@ -1433,7 +1461,7 @@ uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t 
     else
         PT_OCC(0);
 #undef PT_OCC
-    if (rc != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu < 1) per_cu = 1;
     return n_cus * static_cast<uint32_t>(per_cu) * (kExtBlock / 64);
 }
 
@@ -1446,7 +1474,7 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     // waits for node fetches anyway loses less by running thinner for a while: +7 % on 10 M triangles).
     // PT_REFILL_AT: tuning experiments only.
     static const int refill_env = [] {
-        const char *e = std::getenv("PT_REFILL_AT");
+        const char *e = pt::tuning_env("PT_REFILL_AT");
         const int v = e ? std::atoi(e) : 0;
         return v < 0 ? 0 : (v > 64 ? 64 : v);
     }();
@@ -1465,7 +1493,7 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         return;
     }
     const bool counting = tc.nodes_visited != nullptr;
-    static const bool no_lt = std::getenv("PT_NO_LT") != nullptr;  // tuning experiments only
+    static const bool no_lt = pt::tuning_env("PT_NO_LT") != nullptr;  // tuning experiments only
     const bool use_lt = out.light_distance_in_queue && scene.n_lights == 1u && !no_lt && render;
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds);
     const int lds_mode = plan.mode;
@@ -1475,9 +1503,6 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     const size_t lds_bytes = plan.bytes;
 #define PT_LAUNCH_EXTEND2(C, E, L, R, T)                                                                           \
     do {                                                                                                          \
-        if (lds_bytes > 64 * 1024)                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_bvh<C, E, L, R, T>),                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));     \
         hipLaunchKernelGGL((k_extend_bvh<C, E, L, R, T>),                                                         \
                            dim3(resident_grid(k_extend_bvh<C, E, L, R, T>, lds_bytes, g, kExtBlock, "PT_EXT_PER_CU")), \
                            dim3(kExtBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples,            \

@@ -3,6 +3,7 @@
 //   raygen -> [extend -> shade] x max_depth -> accumulate
 // on one HIP stream of one GPU.
 #include "../../include/pathtracer_amd.h"
+#include "tuning.h"
 
 #include <hip/hip_runtime.h>
 
@@ -369,7 +370,7 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         // Slot -> pixel mapping of the queues (kernels.hip, pixel_of_slot): units of 64 pixels, scattered.
         const uint32_t n_px = width * height;
         const bool tiles = (width % 8u == 0u) && (height % 8u == 0u);
-        r->cam.map_mode = std::getenv("PT_NO_SCATTER") ? 0u : (tiles ? 2u : 1u);  // (environment: experiments only)
+        r->cam.map_mode = pt::tuning_env("PT_NO_SCATTER") ? 0u : (tiles ? 2u : 1u);  // (environment: experiments only)
         r->cam.map_units = n_px / 64u;
         r->cam.tiles_x = tiles ? width / 8u : 0u;
         uint32_t stride = static_cast<uint32_t>(r->cam.map_units * 0.6180339887) | 1u;
@@ -557,7 +558,7 @@ uint64_t fnv1a(uint64_t h, const void *data, size_t bytes)
 int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
 {
     const uint32_t T = sc->n_triangles;
-    const bool timing = std::getenv("PT_TIMING") != nullptr;  // stage times of this function on stderr
+    const bool timing = pt::tuning_env("PT_TIMING") != nullptr;  // stage times of this function on stderr
     double t_stage = now_ms();
     auto stage = [&](const char *what) {
         if (timing) std::fprintf(stderr, "upload_scene: %-28s %8.1f ms\n", what, now_ms() - t_stage);
@@ -1009,11 +1010,11 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     pt_renderer *r = new pt_renderer();
     r->cfg = cfg;
     r->device = device;
-    if (const char *e = std::getenv("PT_REGION_SIZE")) {  // tuning experiments only
+    if (const char *e = pt::tuning_env("PT_REGION_SIZE")) {  // tuning experiments only
         int v = std::atoi(e);
         if (v >= 64 && v <= 32768 && v % 64 == 0) r->region_size_env = static_cast<uint32_t>(v);
     }
-    if (const char *e = std::getenv("PT_SCENE_LDS")) r->scene_in_lds = std::atoi(e) != 0;  // tuning experiments only
+    if (const char *e = pt::tuning_env("PT_SCENE_LDS")) r->scene_in_lds = std::atoi(e) != 0;  // tuning experiments only
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         r->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
@@ -1026,7 +1027,7 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     };
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipStreamCreate failed"));
-    r->two_lanes = cfg.batch_streams != 1u && std::getenv("PT_ONE_LANE") == nullptr;  // (environment: experiments only)
+    r->two_lanes = cfg.batch_streams != 1u && pt::tuning_env("PT_ONE_LANE") == nullptr;  // (environment: experiments only)
     if (r->two_lanes) {
         bool ok = hipStreamCreateWithFlags(&r->stream2, hipStreamNonBlocking) == hipSuccess;
         for (int k = 0; k < 2 && ok; ++k) ok = hipEventCreateWithFlags(&r->ev_accum[k], hipEventDisableTiming) == hipSuccess;

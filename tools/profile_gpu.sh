@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof/$TAG
 mkdir -p "$OUT"
 # PROG overrides the profiled command (default: a short bench.py run with the given arguments)
-BENCH=${PROG:-"python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extra --no-alone $*"}
+BENCH=${PROG:-"python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-alone $*"}
 run() { # name, rocprof args...
   local name=$1; shift
   timeout -s KILL ${PASS_LIMIT:-150} rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.json" 2> "$OUT/$name.err"
@@ -17,8 +17,10 @@ run() { # name, rocprof args...
   return $rc
 }
 run kt --kernel-trace --stats || exit 1
-# the same run with one batch at a time (PT_ONE_LANE: one stream, every kernel alone on the GPU)
-PT_ONE_LANE=1 run kt_alone --kernel-trace --stats || exit 1
+# the same run with one batch at a time (one stream, every kernel alone on the GPU)
+BENCH_KEEP=$BENCH; BENCH="$BENCH --batch-streams 1"
+run kt_alone --kernel-trace --stats || exit 1
+BENCH=$BENCH_KEEP
 run pmc_fetch --pmc FETCH_SIZE || exit 1
 run pmc_write --pmc WRITE_SIZE || exit 1
 run pmc_l2 --pmc TCC_HIT_sum TCC_MISS_sum || exit 1

@@ -23,7 +23,7 @@ def short(name):
 # kt_alone: the same run with one batch at a time, every kernel alone on the GPU -- the
 # duration the counters of the PMC passes (which serialise kernels) belong to.
 for sub, title, key in (("kt", "kernel trace (rocprofv3 --kernel-trace --stats), two batches in flight", "avg_launch_us_overlapped"),
-                        ("kt_alone", "kernel trace, one batch at a time (PT_ONE_LANE=1)", "avg_launch_us")):
+                        ("kt_alone", "kernel trace, one batch at a time (--batch-streams 1)", "avg_launch_us")):
     files = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
     if not files:
         continue
