@@ -22,6 +22,20 @@ struct ShadeTriangle {
 };
 static_assert(sizeof(ShadeTriangle) == 80, "ShadeTriangle is five 16-byte lanes");
 
+// x / d for 0 <= x < 2^31: magic = ceil(2^(31 + l) / d), shift = l - 1, l = ceil(log2 d) (Granlund-Montgomery);
+// d = 1 is magic = 0 (the quotient is x itself).
+struct FastDiv {
+    uint32_t magic, shift;
+};
+inline FastDiv make_fast_div(uint32_t d)
+{
+    if (d <= 1u) return FastDiv{0u, 0u};
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned long long m = ((1ull << (31 + l)) + d - 1) / d;  // < 2^32 because d > 2^(l-1)
+    return FastDiv{static_cast<uint32_t>(m), l - 1u};
+}
+
 struct DeviceCamera {
     float eye[3];
     float tan_half_fov;
@@ -32,11 +46,13 @@ struct DeviceCamera {
     float right[3];
     float height_f;
     uint32_t width, height;
-    // Path slot -> pixel within one iteration (see SlotMap in kernels.hip).
+    // Path slot -> pixel within one iteration (pixel_of_slot in kernels.hip).
     uint32_t map_mode;    // 0: slot = pixel; 1: strips of 64 consecutive pixels; 2: tiles of 8 x 8 pixels
     uint32_t map_units;   // strips or tiles that are permuted (the tail beyond them maps to itself)
     uint32_t map_stride;  // unit u of the queue is unit (u * map_stride) mod map_units of the image
     uint32_t tiles_x;     // tiles per image row (mode 2)
+    // Division by three run-time constants without a divide: x / d = umulhi(x, magic) >> shift for x < 2^31.
+    FastDiv div_pixels, div_tiles_x, div_width;
 };
 
 }  // namespace pt

@@ -41,6 +41,7 @@ constexpr int kBlock = 256;
 #endif
 constexpr int kExtBlock = PT_EXT_BLOCK;
 using StackT = PT_STACK_T;
+static_assert(sizeof(StackT) == 4, "a stack entry holds a child code or the end marker, 32 bits");
 // Minimum waves per SIMD the register allocator must leave room for (second
 // argument of __launch_bounds__).
 #ifndef PT_EXTEND_WAVES
@@ -123,13 +124,26 @@ __device__ __forceinline__ float light_distance(const DeviceLight &L, f3 o, f3 d
 // holds the same mix of empty background and geometry and the persistent waves
 // get equal shares of the work.  The image does not depend on the mapping: a
 // sample is a function of (pixel, iteration) only.
+// x / d for x < 2^31 with the magic number the host made for d (device_types.h); rem = x % d.
+__device__ __forceinline__ uint32_t div_by(uint32_t x, uint32_t d, FastDiv f, uint32_t &rem)
+{
+    const uint32_t q = f.magic ? (__umulhi(x, f.magic) >> f.shift) : x;
+    rem = x - q * d;
+    return q;
+}
+
 __device__ __forceinline__ uint32_t pixel_of_slot(const DeviceCamera &cam, uint32_t j)
 {
-    if (cam.map_mode == 0u || (j >> 6) >= cam.map_units) return j;
-    const uint32_t unit = static_cast<uint32_t>((static_cast<unsigned long long>(j >> 6) * cam.map_stride) % cam.map_units);
+    const uint32_t u = j >> 6;
+    if (cam.map_mode == 0u || u >= cam.map_units) return j;
+    // unit u of the queue = unit (u * stride) mod n of the image, stride near n / golden ratio and coprime to n:
+    // any run of consecutive units (a region) is spread evenly over the whole image.  (A cheaper permutation by
+    // bit reversal was measured: traversal 10 % slower -- the waves' shares of the work are less equal.)
+    const uint32_t unit = static_cast<uint32_t>((static_cast<unsigned long long>(u) * cam.map_stride) % cam.map_units);
     const uint32_t in_unit = j & 63u;
     if (cam.map_mode == 1u) return (unit << 6) + in_unit;
-    const uint32_t ty = unit / cam.tiles_x, tx = unit - ty * cam.tiles_x;
+    uint32_t tx;
+    const uint32_t ty = div_by(unit, cam.tiles_x, cam.div_tiles_x, tx);
     return ((ty << 3) + (in_unit >> 3)) * cam.width + (tx << 3) + (in_unit & 7u);
 }
 
@@ -137,8 +151,9 @@ __device__ __forceinline__ uint32_t pixel_of_slot(const DeviceCamera &cam, uint3
 __device__ __forceinline__ float4 primary_p2(const DeviceCamera &cam, uint32_t slot)
 {
     const uint32_t n_pixels = cam.width * cam.height;
-    const uint32_t k = slot / n_pixels;
-    return make_float4(1.f, 1.f, 1.f, __uint_as_float(k * n_pixels + pixel_of_slot(cam, slot - k * n_pixels)));
+    uint32_t j;
+    const uint32_t k = div_by(slot, n_pixels, cam.div_pixels, j);
+    return make_float4(1.f, 1.f, 1.f, __uint_as_float(k * n_pixels + pixel_of_slot(cam, j)));
 }
 
 // frag:866 + frag:306-320.  Path slot i = k * (W*H) + j, j-th slot of iteration k -> pixel_of_slot.
@@ -155,27 +170,35 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, DeviceCamera ca
     const f3 ref = eye + fwd;
     const f3 V = up * cam.tan_half_fov;
     const f3 H = (right * cam.tan_half_fov) * cam.aspect;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
-        const uint32_t k = i / n_pixels;
-        const uint32_t pixel = pixel_of_slot(cam, i - k * n_pixels);
-        const uint32_t y = pixel / cam.width;
-        const uint32_t x = pixel - y * cam.width;
-        const uint32_t iteration = it_first + k * it_stride;
-        uint32_t sx = (iteration + 1u) * x;
-        uint32_t sy = (iteration + 2u) * y;
-        const float jx = rng_next(sx, sy);
-        const float jy = rng_next(sx, sy);
-        float scx = ((static_cast<float>(x) + 0.5f) + jx) / cam.width_f;
-        float scy = ((static_cast<float>(y) + 0.5f) + jy) / cam.height_f;
-        scx = scx * 2.f - 1.f;
-        scy = scy * 2.f - 1.f;
-        const f3 p = (ref + H * scx) + V * scy;
-        const f3 d = normalizem(p - eye);
-        out.p0[i] = make_float4(eye.x, eye.y, eye.z, d.x);
-        out.p1[i] = make_float4(d.y, d.z, __uint_as_float(sx), __uint_as_float(sy));
-        if (sc.n_lights == 1u) out.lt[i] = light_distance(sc.lights[0], eye, d);
-        if (i % region_slots == 0u) counts_out[i / region_slots] = min(region_slots, total - i);
+    // A thread takes slot j of every iteration of the batch: the slot -> pixel arithmetic is done once for all
+    // of them, and the stores of one iteration are still consecutive over the threads.
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n_pixels; j += gridDim.x * kBlock) {
+        const uint32_t pixel = pixel_of_slot(cam, j);
+        uint32_t x;
+        const uint32_t y = div_by(pixel, cam.width, cam.div_width, x);
+        const float fx = static_cast<float>(x) + 0.5f, fy = static_cast<float>(y) + 0.5f;
+        for (uint32_t k = 0; k < n_iterations; ++k) {
+            const uint32_t i = k * n_pixels + j;
+            const uint32_t iteration = it_first + k * it_stride;
+            uint32_t sx = (iteration + 1u) * x;
+            uint32_t sy = (iteration + 2u) * y;
+            const float jx = rng_next(sx, sy);
+            const float jy = rng_next(sx, sy);
+            float scx = (fx + jx) / cam.width_f;
+            float scy = (fy + jy) / cam.height_f;
+            scx = scx * 2.f - 1.f;
+            scy = scy * 2.f - 1.f;
+            const f3 p = (ref + H * scx) + V * scy;
+            const f3 d = normalizem(p - eye);
+            out.p0[i] = make_float4(eye.x, eye.y, eye.z, d.x);
+            out.p1[i] = make_float4(d.y, d.z, __uint_as_float(sx), __uint_as_float(sy));
+            if (sc.n_lights == 1u) out.lt[i] = light_distance(sc.lights[0], eye, d);
+        }
     }
+    // rays per region of the new queue: full regions and a ragged last one
+    const uint32_t n_regions = (total + region_slots - 1u) / region_slots;
+    for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < n_regions; r += gridDim.x * kBlock)
+        counts_out[r] = min(region_slots, total - r * region_slots);
 }
 
 // ---------------------------------------------------------------- extend
@@ -192,6 +215,7 @@ struct Hit {
     int id;  // original triangle index (| kClassBit for a surface that is not purely diffuse), -1 none
 };
 constexpr int kClassBit = 1 << 30;
+constexpr int kFinished = static_cast<int>(0x80000000u);  // traversal state of a lane with nothing left to visit
 constexpr int kIdMask = kClassBit - 1;
 
 // frag:393-415 with n and dot(n,v0) hoisted (same operations, same bits).
@@ -333,7 +357,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 // BVH traversal.  Each lane keeps its stack of deferred children in LDS,
 // laid out [entry][lane] so that a push/pop of all lanes touches consecutive
 // banks.  The stack can never hold more than one entry per inner level of the
-// tree; the host passes stack_entries >= tree depth.
+// tree, plus the end marker in entry 0; the host passes stack_entries > tree depth.
 //
 // Box test: the reference accepts hit points that lie a few ulp outside the
 // exact triangle, so a box may only be culled when the ray misses it by a
@@ -416,14 +440,18 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
     uint32_t nxt_n = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
     {
         // per-lane ray state
-        bool active = false, done = false, gen = false;
+        // A lane's traversal state is `node` (>= 0: an inner node to test; < 0: a leaf code to test; kFinished:
+        // nothing left) and `sp`, the number of deferred children on its stack.  Entry 0 of every stack holds
+        // kFinished, so the pop that finds nothing deferred yields the finished state without a test.
+        bool active = false, gen = false;
         uint32_t slot = 0;
         f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
         float ix = 0.f, iy = 0.f, iz = 0.f, cnx = 0.f, cny = 0.f, cnz = 0.f, cfx = 0.f, cfy = 0.f, cfz = 0.f;
         bool negx = false, negy = false, negz = false;
         Hit h{__builtin_inff(), -1};
         float ltv = __uint_as_float(kNoLightBits);  // the word beside the ray: |ltv| = distance to the light or NaN, sign = poisoned path
-        int node = 0, sp = 0;
+        int node = kFinished, sp = 1;
+        stack[tid] = static_cast<StackT>(kFinished);
 
         for (;;) {
             // ---- hand fresh rays to idle lanes
@@ -484,8 +512,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                         h.t = (USE_LT && fabsf(ltv) >= 0.f) ? fabsf(ltv) : __builtin_inff();
                         h.id = -1;
                         node = 0;
-                        sp = 0;
-                        done = false;
+                        sp = 1;
                         active = true;
                     }
                 }
@@ -503,12 +530,15 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
             }
 
             // ---- phase A: inner nodes
-            while (__ballot(active && !done && node >= 0) != 0ull) {
+            for (;;) {
+                const bool go = node >= 0;
+                const unsigned long long going = __ballot(go);
+                if (going == 0ull) break;
                 if (COUNT) {
                     dg[0] += 1;
-                    dg[1] += __popcll(__ballot(active && !done && node >= 0));
+                    dg[1] += __popcll(going);
                 }
-                if (active && !done && node >= 0) {
+                if (go) {
                     float4 n0, n1, n2, n3;
                     if (SCENE_LDS >= 2 || (SCENE_LDS == 1 && static_cast<uint32_t>(node) < n_lds_nodes)) {
                         const float4 *np = lds_nodes + PT_LDS_STRIDE * static_cast<size_t>(node);
@@ -531,18 +561,16 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                     const float tf1 = fminf(fminf(fmaf(x1x, ix, cfx), fmaf(x1y, iy, cfy)), fminf(fmaf(x1z, iz, cfz), h.t));
                     const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
                     const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                    // The nearer of the children that are hit is visited next, the other one deferred; with no
+                    // child hit the lane takes up its last deferred child (or finds the end marker).
+                    const bool second_first = hit1 && !(hit0 && tn0 <= tn1);
+                    const int near_c = second_first ? c1 : c0, far_c = second_first ? c0 : c1;
                     if (hit0 && hit1) {
-                        const bool first0 = tn0 <= tn1;
-                        stack[sp * kExtBlock + tid] = static_cast<StackT>(first0 ? c1 : c0);
+                        stack[sp * kExtBlock + tid] = static_cast<StackT>(far_c);
                         ++sp;
-                        node = first0 ? c0 : c1;
-                    } else if (hit0) {
-                        node = c0;
-                    } else if (hit1) {
-                        node = c1;
-                    } else if (sp == 0) {
-                        done = true;
-                    } else {
+                    }
+                    node = near_c;
+                    if (!(hit0 || hit1)) {
                         --sp;
                         node = stack[sp * kExtBlock + tid];
                     }
@@ -551,7 +579,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
 
             // ---- phase B: leaves
             if (COUNT) {
-                const uint32_t c = (active && !done) ? ((~static_cast<uint32_t>(node)) & 7u) : 0u;
+                const uint32_t c = (node != kFinished) ? ((~static_cast<uint32_t>(node)) & 7u) : 0u;
                 uint32_t mx = c;
                 for (int off = 32; off > 0; off >>= 1) mx = max(mx, static_cast<uint32_t>(__shfl_xor(mx, off)));
                 uint32_t sm = c;
@@ -559,7 +587,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 dg[2] += mx;
                 dg[3] += sm;
             }
-            if (active && !done) {
+            if (node != kFinished) {
                 const uint32_t code = ~static_cast<uint32_t>(node);
                 const uint32_t first = code >> 3, cnt = code & 7u;
                 for (uint32_t j = 0; j < cnt; ++j) {
@@ -569,12 +597,8 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                         test_triangle<false>(sc.triangles + 4 * static_cast<size_t>(first + j), o, d, h);
                 }
                 if (COUNT) my_tris += cnt;
-                if (sp == 0) {
-                    done = true;
-                } else {
-                    --sp;
-                    node = stack[sp * kExtBlock + tid];
-                }
+                --sp;
+                node = stack[sp * kExtBlock + tid];
             }
 
             // ---- finished rays: lights, result, lane becomes idle
@@ -582,7 +606,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
             float hit_t = 0.f;
             int hit_code = -1;
             bool other = false;
-            if (active && done) {
+            if (active && node == kFinished) {
                 if (EXACT && !(h.t < __builtin_inff())) {
                     for (uint32_t j = 0; j < sc.n_triangles; ++j) {
                         const float4 *tp = sc.triangles + 4 * static_cast<size_t>(j);

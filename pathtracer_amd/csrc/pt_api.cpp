@@ -377,6 +377,9 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         while (r->cam.map_units > 1u && gcd_u32(stride, r->cam.map_units) != 1u) stride += 2u;
         r->cam.map_stride = r->cam.map_units > 1u ? stride % r->cam.map_units : 1u;
         if (r->cam.map_stride == 0u || r->cam.map_units < 2u) r->cam.map_mode = 0u;
+        r->cam.div_pixels = pt::make_fast_div(n_px);
+        r->cam.div_tiles_x = pt::make_fast_div(std::max(1u, r->cam.tiles_x));
+        r->cam.div_width = pt::make_fast_div(width);
     }
     return PT_OK;
 }
@@ -680,7 +683,7 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
     r->bvh_build_ms = now_ms() - t0 - device_upload_ms;
     stage("BVH");
     r->bvh_builder = device_build ? 1u : 0u;
-    r->stack_entries = std::max<uint32_t>(4, (r->bvh_depth + 3u) & ~3u);  // LDS stack: one entry per inner level, in fours
+    r->stack_entries = std::max<uint32_t>(4, (r->bvh_depth + 1u + 3u) & ~3u);  // LDS stack: the end marker + one entry per inner level, in fours
 
     std::vector<pt::ShadeTriangle> shade(device_build ? 0 : T);
     for (uint32_t t = 0; t < static_cast<uint32_t>(shade.size()); ++t) {
@@ -1526,7 +1529,7 @@ int pt_bvh_inspect(const pt_scene_desc *sc, pt_bvh_info *info)
     info->n_triangles = T;
     info->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
     info->depth = bvh.depth;
-    info->stack_entries = std::max<uint32_t>(4, (bvh.depth + 3u) & ~3u);
+    info->stack_entries = std::max<uint32_t>(4, (bvh.depth + 1u + 3u) & ~3u);
     info->sah_cost = bvh.sah_cost;
 
     // Walk the tree: boxes must enclose everything below them; leaves must
