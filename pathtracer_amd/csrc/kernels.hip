@@ -34,11 +34,6 @@ constexpr int kBlock = 256;
 #ifndef PT_STACK_T
 #define PT_STACK_T int
 #endif
-// 16-byte lanes between consecutive records of the LDS copy of the scene (4 = packed; 5 spreads
-// consecutive records over all banks).
-#ifndef PT_LDS_STRIDE
-#define PT_LDS_STRIDE 4
-#endif
 constexpr int kExtBlock = PT_EXT_BLOCK;
 using StackT = PT_STACK_T;
 static_assert(sizeof(StackT) == 4, "a stack entry holds a child code or the end marker, 32 bits");
@@ -240,7 +235,7 @@ __device__ __forceinline__ void test_triangle(const float4 *__restrict__ tp, f3 
         if (st < 0.f || st > h.t) return;
     } else {
         // v_cmp_class: -0, +0, positive denormal, positive normal
-        if (!__builtin_amdgcn_class(st, 0x1E0) || st > h.t) return;
+        if (!__builtin_amdgcn_classf(st, 0x1E0) || st > h.t) return;
     }
     const f3 Q = mk(o.x + st * d.x, o.y + st * d.y, o.z + st * d.z);
     if (dotm(crossm(v1 - v0, Q - v0), n) < 0.f) return;
@@ -404,21 +399,26 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                                                         float4 *__restrict__ hit_list, float4 *__restrict__ samples,
                                                         uint32_t last_segment,
                                                         TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
-                                                        uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t sample_tag,
-                                                        DeviceCamera cam, uint32_t primary)
+                                                        uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
+                                                        uint32_t sample_tag, DeviceCamera cam, uint32_t primary)
 {
+    // lds_stride: 16-byte lanes between consecutive records of the LDS copy of the scene.  4 = packed: the four
+    // ds_read_b128 of a 64-byte record all start on banks 0, 16, 32 or 48, so the 16 lanes such a read serves at
+    // a time collide four deep on average.  5 spreads consecutive records over all banks (records of 80 bytes,
+    // the last lane unused); the host asks for it when the part of the scene kept in LDS still fits that way.
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     extern __shared__ float4 lds[];
     StackT *stack = reinterpret_cast<StackT *>(lds);           // stack_entries * kExtBlock entries, [entry][lane]
     float4 *lds_nodes = lds + (stack_entries * kExtBlock * sizeof(StackT)) / 16;  // the first n_lds_nodes nodes
-    float4 *lds_tris = lds_nodes + PT_LDS_STRIDE * static_cast<size_t>(n_lds_nodes);  // all triangles (SCENE_LDS == 2)
+    float4 *lds_tris = lds_nodes + lds_stride * static_cast<size_t>(n_lds_nodes);
+    const uint32_t lds_rec_bytes = 16u * lds_stride;  // all triangles (SCENE_LDS == 2)
     const uint32_t tid = threadIdx.x;
     if (SCENE_LDS >= 1) {
         for (uint32_t i = tid; i < 4u * n_lds_nodes; i += kExtBlock)
-            lds_nodes[(i >> 2) * PT_LDS_STRIDE + (i & 3u)] = sc.nodes[i];
+            lds_nodes[(i >> 2) * lds_stride + (i & 3u)] = sc.nodes[i];
         if (SCENE_LDS == 2)
             for (uint32_t i = tid; i < 4u * sc.n_triangles; i += kExtBlock)
-                lds_tris[(i >> 2) * PT_LDS_STRIDE + (i & 3u)] = sc.triangles[i];
+                lds_tris[(i >> 2) * lds_stride + (i & 3u)] = sc.triangles[i];
         __syncthreads();
     }
     const uint32_t n_waves = gridDim.x * (kExtBlock / 64);
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 if (go) {
                     float4 n0, n1, n2, n3;
                     if (SCENE_LDS >= 2 || (SCENE_LDS == 1 && static_cast<uint32_t>(node) < n_lds_nodes)) {
-                        const float4 *np = lds_nodes + PT_LDS_STRIDE * static_cast<size_t>(node);
+                        const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(lds_nodes) + __umul24(static_cast<uint32_t>(node), lds_rec_bytes));
                         n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
                     } else {
                         const float4 *np = sc.nodes + 4 * static_cast<size_t>(node);
@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 const uint32_t first = code >> 3, cnt = code & 7u;
                 for (uint32_t j = 0; j < cnt; ++j) {
                     if (SCENE_LDS == 2)
-                        test_triangle<false>(lds_tris + PT_LDS_STRIDE * static_cast<size_t>(first + j), o, d, h);
+                        test_triangle<false>(reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(lds_tris) + __umul24(first + j, lds_rec_bytes)), o, d, h);
                     else
                         test_triangle<false>(sc.triangles + 4 * static_cast<size_t>(first + j), o, d, h);
                 }
@@ -1439,6 +1439,7 @@ namespace {
 struct LdsPlan {
     int mode;
     uint32_t n_lds_nodes;
+    uint32_t stride;  // 16-byte lanes per record in LDS: 5 (spread over the banks) when everything wanted still fits, else 4
     size_t bytes;
 };
 LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds)
@@ -1448,20 +1449,30 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
         return static_cast<size_t>(e ? std::atoi(e) : 40) * 1024;
     }();
     const size_t stack_bytes = static_cast<size_t>(stack_entries) * kExtBlock * sizeof(StackT);
-    const size_t record = 16 * PT_LDS_STRIDE;
-    const size_t node_bytes = static_cast<size_t>(n_nodes) * record, tri_bytes = static_cast<size_t>(scene.n_triangles) * record;
-    LdsPlan p{0, 0, 0};
-    if (scene_in_lds && stack_bytes + node_bytes + tri_bytes <= budget) {
-        p.mode = 2;
-        p.n_lds_nodes = n_nodes;
-    } else if (scene_in_lds && stack_bytes + node_bytes <= budget) {
-        p.mode = 3;
-        p.n_lds_nodes = n_nodes;
-    } else if (scene_in_lds && stack_bytes + 64 * record <= budget) {
-        p.mode = 1;
-        p.n_lds_nodes = static_cast<uint32_t>((budget - stack_bytes) / record);
+    LdsPlan p{0, 0, 4, 0};
+    // first with records spread over the banks (80 bytes each), then packed (64): the whole scene, else all
+    // nodes; a cached top of the tree is always packed (there capacity counts for more than conflicts)
+    for (uint32_t stride : {5u, 4u}) {
+        const size_t record = 16 * stride;
+        const size_t node_bytes = static_cast<size_t>(n_nodes) * record, tri_bytes = static_cast<size_t>(scene.n_triangles) * record;
+        if (scene_in_lds && stack_bytes + node_bytes + tri_bytes <= budget) {
+            p = LdsPlan{2, n_nodes, stride, stack_bytes + node_bytes + tri_bytes};
+            return p;
+        }
     }
-    p.bytes = stack_bytes + p.n_lds_nodes * record + (p.mode == 2 ? tri_bytes : 0);
+    for (uint32_t stride : {5u, 4u}) {
+        const size_t record = 16 * stride;
+        const size_t node_bytes = static_cast<size_t>(n_nodes) * record;
+        if (scene_in_lds && stack_bytes + node_bytes <= budget) {
+            p = LdsPlan{3, n_nodes, stride, stack_bytes + node_bytes};
+            return p;
+        }
+    }
+    if (scene_in_lds && stack_bytes + 64 * 64 <= budget) {
+        p.mode = 1;
+        p.n_lds_nodes = static_cast<uint32_t>((budget - stack_bytes) / 64);
+    }
+    p.bytes = stack_bytes + static_cast<size_t>(p.n_lds_nodes) * 64;
     return p;
 }
 }  // namespace
@@ -1530,7 +1541,7 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         hipLaunchKernelGGL((k_extend_bvh<C, E, L, R, T>),                                                         \
                            dim3(resident_grid(k_extend_bvh<C, E, L, R, T>, lds_bytes, g, kExtBlock, "PT_EXT_PER_CU")), \
                            dim3(kExtBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples,            \
-                           last, tc, n_nodes, refill_at, stack_entries, n_lds_nodes, out.sample_tag,   \
+                           last, tc, n_nodes, refill_at, stack_entries, n_lds_nodes, plan.stride, out.sample_tag,   \
                            primary_cam, primary);            \
     } while (0)
 #define PT_LAUNCH_EXTEND1(L)                                                                                       \
