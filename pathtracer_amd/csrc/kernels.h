@@ -69,9 +69,20 @@ struct LaunchShape {
     uint32_t wave_items;  // work available to the region kernels, in waves' worth (regions)
 };
 
+// What changes from one batch to the next (and with the camera), kept in a small block of device memory that
+// the kernels of a batch read, so that their arguments stay the same from batch to batch.  launch_set_batch writes
+// the block in stream order.
+struct BatchParams {
+    DeviceCamera cam;
+    uint32_t it_first;    // iterationCount of the batch's first sample (renderer.cpp:132)
+    uint32_t sample_tag;  // written into the w lane of every sample of this batch (see launch_accumulate)
+    uint32_t pad[2];
+};
+void launch_set_batch(hipStream_t s, BatchParams *params, const DeviceCamera &cam, uint32_t it_first, uint32_t sample_tag);
+
 // counts_out: n_regions live counts of bounce 0.
-void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, DeviceCamera cam, uint32_t it_first,
-                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_size);
+void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, const BatchParams *params, uint32_t it_stride,
+                   uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_size);
 
 // Where extend puts its results.
 //  render = false: hit_list is written as a float2 array, results[slot] = (t, hit code), for every ray
@@ -87,10 +98,10 @@ struct ExtendOutput {
     bool render;
     bool last_segment;
     bool exact_parallel;
-    uint32_t sample_tag = 0;  // written into the w lane of every sample of this batch (see launch_accumulate)
+    const BatchParams *params = nullptr;  // the batch's block (render = true): sample tag, camera
     // First segment of a batch made by launch_raygen: lane p2 (throughput 1, the path's own sample slot) is not
     // stored for it but derived from the queue slot with the camera's slot -> pixel mapping.
-    const DeviceCamera *primary_of = nullptr;
+    bool primary = false;
 };
 
 // stack_entries: entries of the per-lane traversal stack in LDS (>= BVH depth).
@@ -106,7 +117,7 @@ uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t 
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
                   const float4 *hit_list, PathQueue out, float4 *samples /* receives the sample of a path whose ray went non-finite */,
-                  uint32_t sample_tag, const DeviceCamera *primary_of /* as in ExtendOutput, may be null */,
+                  const BatchParams *params, bool primary /* as in ExtendOutput */,
                   bool final_bounce /* the hits of the last allowed segment: nothing survives, only non-finite samples are written */);
 
 // The sample buffer is never cleared: a path that ends on a light writes (radiance, tag) with the tag of its
@@ -115,8 +126,8 @@ void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, floa
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
                        uint32_t pitch, unsigned long long *segments_total,
                        unsigned long long *shade_totals /* [0] surface hits shaded, [1] 64-lane batches formed */,
-                       unsigned long long *nan_counter, uint8_t *rgba8 /* may be null */, uint32_t it_first,
-                       uint32_t it_stride, uint32_t sample_tag);
+                       unsigned long long *nan_counter, uint8_t *rgba8 /* may be null */, const BatchParams *params,
+                       uint32_t it_stride);
 
 // hits -> int32 hit codes / t / directions in pixel order for one iteration.
 // cam: the camera whose raygen made the rays (its slot -> pixel mapping orders the output by pixel); null: rays

@@ -152,10 +152,21 @@ __device__ __forceinline__ float4 primary_p2(const DeviceCamera &cam, uint32_t s
 }
 
 // frag:866 + frag:306-320.  Path slot i = k * (W*H) + j, j-th slot of iteration k -> pixel_of_slot.
-__global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, DeviceCamera cam, uint32_t it_first, uint32_t it_stride,
+__global__ void __launch_bounds__(64) k_set_batch(BatchParams *params, DeviceCamera cam, uint32_t it_first, uint32_t sample_tag)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        params->cam = cam;
+        params->it_first = it_first;
+        params->sample_tag = sample_tag;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, const BatchParams *__restrict__ bp, uint32_t it_stride,
                                                     uint32_t n_iterations, PathQueue out, uint32_t *counts_out,
                                                     uint32_t region_slots)
 {
+    const DeviceCamera cam = bp->cam;
+    const uint32_t it_first = bp->it_first;
     const uint32_t n_pixels = cam.width * cam.height;
     const uint32_t total = n_pixels * n_iterations;
     const f3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
@@ -303,8 +314,9 @@ template <bool RENDER>
 __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg, PathQueue q,
                                                          float4 *__restrict__ hit_list, float4 *__restrict__ samples,
                                                          uint32_t last_segment,
-                                                         uint32_t sample_tag, DeviceCamera cam, uint32_t primary)
+                                                         const BatchParams *__restrict__ bp, uint32_t primary)
 {
+    const uint32_t sample_tag = RENDER ? bp->sample_tag : 0u;
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
@@ -331,7 +343,7 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
             if (!RENDER) {
                 results[i] = make_float2(t, __int_as_float(code));
             } else if (code <= -2) {
-                const float4 c = primary ? primary_p2(cam, i) : q.p2[i];
+                const float4 c = primary ? primary_p2(bp->cam, i) : q.p2[i];
                 const float *rad = sc.lights[-(code + 2)].radiance;
                 const f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
                 // a non-finite sample is left to the accumulate kernel (which drops and counts it)
@@ -400,8 +412,9 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                                                         uint32_t last_segment,
                                                         TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
                                                         uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
-                                                        uint32_t sample_tag, DeviceCamera cam, uint32_t primary)
+                                                        const BatchParams *__restrict__ bp, uint32_t primary)
 {
+    const uint32_t sample_tag = RENDER ? bp->sample_tag : 0u;
     // lds_stride: 16-byte lanes between consecutive records of the LDS copy of the scene.  4 = packed: the four
     // ds_read_b128 of a 64-byte record all start on banks 0, 16, 32 or 48, so the 16 lanes such a read serves at
     // a time collide four deep on average.  5 spreads consecutive records over all banks (records of 80 bytes,
@@ -627,7 +640,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                     results[slot] = make_float2(hit_t, __int_as_float(hit_code));
                 } else if (hit_code <= -2) {
                     // passCol = attenuation * intensity (frag:878-882, :901)
-                    const float4 c = primary ? primary_p2(cam, slot) : q.p2[slot];
+                    const float4 c = primary ? primary_p2(bp->cam, slot) : q.p2[slot];
                     const float *rad = sc.lights[-(hit_code + 2)].radiance;
                     const f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
                     // a non-finite sample is left to the accumulate kernel (which drops and counts it)
@@ -1041,9 +1054,10 @@ __device__ __forceinline__ f3 interpolated_normal(float4 s0, float4 s1, float4 s
 // is evaluated only because a non-finite value it produces is the path's sample.
 __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, Regions rg, PathQueue in,
                                                    const float4 *__restrict__ hit_list, PathQueue out,
-                                                   float4 *__restrict__ samples, uint32_t sample_tag,
-                                                   DeviceCamera cam, uint32_t primary, uint32_t final_bounce)
+                                                   float4 *__restrict__ samples, const BatchParams *__restrict__ bp,
+                                                   uint32_t primary, uint32_t final_bounce)
 {
+    const uint32_t sample_tag = bp->sample_tag;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
     uint32_t k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -1094,7 +1108,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
         if (take0 || take1) {
             const float4 rec = hit_list[region_base + (take1 ? last_slot - j : j)];
             const uint32_t i = region_base + __float_as_uint(rec.z);
-            const float4 a = in.p0[i], b = in.p1[i], c = primary ? primary_p2(cam, i) : in.p2[i];
+            const float4 a = in.p0[i], b = in.p1[i], c = primary ? primary_p2(bp->cam, i) : in.p2[i];
             const int code = __float_as_int(rec.y);
             const f3 thr = mk(c.x, c.y, c.z);
             {
@@ -1189,9 +1203,10 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
                                                         unsigned long long *__restrict__ segments_total,
                                                         unsigned long long *__restrict__ shade_totals,
                                                         unsigned long long *__restrict__ nan_counter,
-                                                        uint8_t *__restrict__ rgba8, uint32_t it_first, uint32_t it_stride,
-                                                        uint32_t sample_tag)
+                                                        uint8_t *__restrict__ rgba8, const BatchParams *__restrict__ bp,
+                                                        uint32_t it_stride)
 {
+    const uint32_t it_first = bp->it_first, sample_tag = bp->sample_tag;
     {
         // surface hits shaded in this batch and the 64-lane batches the shade kernel formed of them
         // (rows n_rows + 1 ... 2 * n_rows - 1 hold the packed hit counts of the bounces that are shaded)
@@ -1425,10 +1440,15 @@ uint32_t resident_grid(K kernel, size_t lds_bytes, LaunchShape g, int block = kB
 }
 }  // namespace
 
-void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, DeviceCamera cam, uint32_t it_first,
-                   uint32_t it_stride, uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_size)
+void launch_set_batch(hipStream_t s, BatchParams *params, const DeviceCamera &cam, uint32_t it_first, uint32_t sample_tag)
 {
-    hipLaunchKernelGGL(k_raygen, dim3(g.blocks), dim3(kBlock), 0, s, scene, cam, it_first, it_stride, n_iterations, out,
+    hipLaunchKernelGGL(k_set_batch, dim3(1), dim3(64), 0, s, params, cam, it_first, sample_tag);
+}
+
+void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, const BatchParams *params, uint32_t it_stride,
+                   uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_size)
+{
+    hipLaunchKernelGGL(k_raygen, dim3(g.blocks), dim3(kBlock), 0, s, scene, params, it_stride, n_iterations, out,
                        counts_out, region_size);
 }
 
@@ -1514,17 +1534,16 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         return v < 0 ? 0 : (v > 64 ? 64 : v);
     }();
     const bool render = out.render;
-    const uint32_t primary = out.primary_of ? 1u : 0u;
-    const DeviceCamera primary_cam = out.primary_of ? *out.primary_of : DeviceCamera{};
+    const uint32_t primary = out.primary ? 1u : 0u;
     const bool exact_parallel = out.exact_parallel;
     const uint32_t last = out.last_segment ? 1u : 0u;
     if (!use_bvh) {
         if (render)
             hipLaunchKernelGGL(k_extend_scan<true>, dim3(resident_grid(k_extend_scan<true>, 0, g)), dim3(kBlock), 0, s, scene,
-                               regions, q, out.hit_list, out.samples, last, out.sample_tag, primary_cam, primary);
+                               regions, q, out.hit_list, out.samples, last, out.params, primary);
         else
             hipLaunchKernelGGL(k_extend_scan<false>, dim3(resident_grid(k_extend_scan<false>, 0, g)), dim3(kBlock), 0, s, scene,
-                               regions, q, out.hit_list, out.samples, last, out.sample_tag, primary_cam, primary);
+                               regions, q, out.hit_list, out.samples, last, out.params, primary);
         return;
     }
     const bool counting = tc.nodes_visited != nullptr;
@@ -1541,8 +1560,8 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         hipLaunchKernelGGL((k_extend_bvh<C, E, L, R, T>),                                                         \
                            dim3(resident_grid(k_extend_bvh<C, E, L, R, T>, lds_bytes, g, kExtBlock, "PT_EXT_PER_CU")), \
                            dim3(kExtBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples,            \
-                           last, tc, n_nodes, refill_at, stack_entries, n_lds_nodes, plan.stride, out.sample_tag,   \
-                           primary_cam, primary);            \
+                           last, tc, n_nodes, refill_at, stack_entries, n_lds_nodes, plan.stride, out.params,   \
+                           primary);            \
     } while (0)
 #define PT_LAUNCH_EXTEND1(L)                                                                                       \
     do {                                                                                                          \
@@ -1576,23 +1595,21 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
 }
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
-                  const float4 *hit_list, PathQueue out, float4 *samples, uint32_t sample_tag,
-                  const DeviceCamera *primary_of, bool final_bounce)
+                  const float4 *hit_list, PathQueue out, float4 *samples, const BatchParams *params, bool primary,
+                  bool final_bounce)
 {
     hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g, kBlock, "PT_SHADE_PER_CU")), dim3(kBlock), 0, s, scene, regions, in, hit_list, out,
-                       samples, sample_tag, primary_of ? *primary_of : DeviceCamera{}, primary_of ? 1u : 0u,
-                       final_bounce ? 1u : 0u);
+                       samples, params, primary ? 1u : 0u, final_bounce ? 1u : 0u);
 }
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
                        uint32_t pitch, unsigned long long *segments_total, unsigned long long *shade_totals,
-                       unsigned long long *nan_counter, uint8_t *rgba8, uint32_t it_first, uint32_t it_stride,
-                       uint32_t sample_tag)
+                       unsigned long long *nan_counter, uint8_t *rgba8, const BatchParams *params, uint32_t it_stride)
 {
     hipLaunchKernelGGL(k_accumulate, dim3(g.blocks), dim3(kBlock), 0, s, samples, sum, n_pixels, n_iterations, counts,
                        n_rows, n_regions, pitch, segments_total, shade_totals, nan_counter,
-                       rgba8, it_first, it_stride, sample_tag);
+                       rgba8, params, it_stride);
 }
 
 void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *hits, int32_t *ids,

@@ -159,6 +159,7 @@ struct pt_renderer {
     uint32_t region_pitch = 0;                // regions the queues hold at full capacity
     uint32_t region_size = 1024;              // slots per region, chosen from the batch size and the resident waves
     uint32_t region_size_env = 0;             // set through the environment (experiments)
+    uint32_t extend_waves = 0;                // waves of the traversal kernel resident at once
     uint64_t scene_hash = 0;                  // FNV-1a over the scene arrays (checkpoint compatibility)
     uint8_t *d_rgba8 = nullptr;               // emulated 8-bit accumulation texture (cfg.emulate_rgba8)
     uint32_t bvh_builder = 0;                 // the builder that made the tree (0 host, 1 device)
@@ -200,6 +201,9 @@ struct pt_renderer {
         int kernel;  // 0 raygen, 1 extend, 2 shade, 3 accumulate
     };
     std::vector<TimedLaunch> timed;
+
+    // per-batch scalars on the device, one block per set of batch buffers (kernels.h, BatchParams)
+    pt::BatchParams *d_params = nullptr;
 };
 
 namespace {
@@ -308,6 +312,7 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         const uint32_t waves = r->cfg.use_bvh
                                    ? pt::extend_resident_waves(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds)
                                    : r->n_cus * 32u;
+        r->extend_waves = waves;
         size_t m = std::max<size_t>(1, (r->capacity + size_t(waves) * 1024) / (size_t(waves) * 2048));
         size_t size = (r->capacity + waves * m - 1) / (waves * m);
         size = std::max<size_t>(256, (size + 63) & ~size_t(63));
@@ -389,11 +394,30 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
 // regions (k * stride) mod n_regions, k = w, w + n_waves, ...; a stride near
 // the golden ratio of n_regions, coprime to it, scatters neighbouring image
 // areas over different waves.
+// Slots per region for a launch over n_items queue slots.  A full batch uses the size the buffers were laid out
+// for; a smaller one (the reference's one sample per draw) gets smaller regions, so that it still spreads over
+// all resident waves: the same rule as in alloc_paths, within what the count rows and the hit list can hold.
+uint32_t region_size_for(const pt_renderer *r, size_t n_items)
+{
+    if (n_items >= r->capacity || r->region_size_env) return r->region_size;
+    const size_t waves = std::max<uint32_t>(1, r->extend_waves);
+    size_t m = std::max<size_t>(1, (n_items + waves * 1024) / (waves * 2048));
+    size_t size = (n_items + waves * m - 1) / (waves * m);
+    size = std::max<size_t>(256, (size + 63) & ~size_t(63));
+    // no more regions than a row of counts has entries
+    const size_t at_least = (n_items + r->region_pitch - 1) / std::max<uint32_t>(1, r->region_pitch);
+    size = std::max(size, (at_least + 63) & ~size_t(63));
+    size = std::min<size_t>(size, r->region_size);
+    // the hit list holds region_pitch regions of the full size: whole regions of the smaller size must fit in it
+    if (((n_items + size - 1) / size) * size > static_cast<size_t>(r->region_pitch) * r->region_size) return r->region_size;
+    return static_cast<uint32_t>(size);
+}
+
 pt::Regions regions_for(const pt_renderer *r, size_t n_items, uint32_t row_in, int row_out, uint32_t *counts = nullptr)
 {
     if (!counts) counts = r->d_counts;
     pt::Regions g;
-    g.size = r->region_size;
+    g.size = region_size_for(r, n_items);
     g.n_regions = static_cast<uint32_t>(std::max<size_t>(1, (n_items + g.size - 1) / g.size));
     uint32_t stride = static_cast<uint32_t>(g.n_regions * 0.6180339887) | 1u;
     while (gcd_u32(stride, g.n_regions) != 1u) stride += 2u;
@@ -408,7 +432,7 @@ pt::LaunchShape shape_for(const pt_renderer *r, size_t work_items)
 {
     const size_t blocks_needed = (work_items + 255) / 256;
     const size_t cap = static_cast<size_t>(r->n_cus) * 8;
-    const size_t regions = (work_items + r->region_size - 1) / r->region_size;
+    const size_t regions = (work_items + region_size_for(r, work_items) - 1) / region_size_for(r, work_items);
     return pt::LaunchShape{static_cast<uint32_t>(std::max<size_t>(1, std::min(blocks_needed, cap))), r->n_cus,
                            static_cast<uint32_t>(std::max<size_t>(1, regions))};
 }
@@ -464,31 +488,23 @@ void drain_events(pt_renderer *r)
     r->timed.clear();
 }
 
-// One batch of `kb` iterations starting at partition index `first_k`.
-int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
+// The launches of one batch up to (not including) its accumulate kernel: raygen, then extend / shade per bounce.
+// Everything that differs from batch to batch is read from the lane's BatchParams block, so for a given lane and
+// batch size these launches are always the same.
+void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
 {
     const uint32_t depth = r->cfg.max_depth;
-    const size_t n_pixels = static_cast<size_t>(r->width) * r->height;
-    const size_t n_paths = n_pixels * kb;
-    const uint32_t it_first = static_cast<uint32_t>(r->rank + first_k * r->world);
+    const size_t n_paths = static_cast<size_t>(r->width) * r->height * kb;
     pt::TraversalCounters tc{nullptr, nullptr, nullptr};
     if (r->cfg.profile & 2u) tc = pt::TraversalCounters{r->d_counters + 2, r->d_counters + 3, r->d_counters + 4};
     const pt::LaunchShape g = shape_for(r, n_paths);
-    // the set of batch buffers this batch runs in, and its stream
-    const uint32_t lane = r->lanes_in_use == 2u ? (r->next_lane++ & 1u) : 0u;
-    hipStream_t st = lane ? r->stream2 : r->stream;
     pt::PathQueue *q = lane ? r->q2 : r->q;
     float4 *d_hits = lane ? r->d_hits2 : r->d_hits, *d_samples = lane ? r->d_samples2 : r->d_samples;
     uint32_t *d_counts = lane ? r->d_counts2 : r->d_counts;
-    uint32_t &tag = lane ? r->sample_tag2 : r->sample_tag;
-    if (lane && r->ops_pending) {
-        PT_HIP(hipStreamWaitEvent(st, r->ev_ops, 0));
-        r->ops_pending = false;
-    }
-    if (++tag == 0u) tag = 1u;  // 0 is the tag of the cleared buffer
+    const pt::BatchParams *bp = r->d_params + lane;
     {
         Timed t(r, 0, st);
-        pt::launch_raygen(st, g, r->view, r->cam, it_first, r->world, kb, q[0], d_counts, r->region_size);
+        pt::launch_raygen(st, g, r->view, bp, r->world, kb, q[0], d_counts, region_size_for(r, n_paths));
     }
     // The reference's non-finite samples one for one (the 8-bit emulation needs them, profile bit 2 asks for
     // them): rays that escape are checked for planes they are exactly parallel to (a "hit" at t = inf in the
@@ -504,7 +520,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
         const int hit_row = static_cast<int>(depth + 1 + b);
         {
             Timed t(r, 1, st);
-            pt::ExtendOutput eo{true, d_hits, d_samples, true, last, exact_samples, tag, b == 0 ? &r->cam : nullptr};
+            pt::ExtendOutput eo{true, d_hits, d_samples, true, last, exact_samples, bp, b == 0};
             pt::launch_extend(st, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, hit_row, d_counts), in,
                               eo, tc, r->n_nodes, r->scene_in_lds);
         }
@@ -512,9 +528,34 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
             Timed t(r, 2, st);
             pt::launch_shade(st, g, r->view,
                              regions_for(r, n_paths, static_cast<uint32_t>(hit_row), static_cast<int>(b) + 1, d_counts), in, d_hits,
-                             out, d_samples, tag, b == 0 ? &r->cam : nullptr, final_shade);
+                             out, d_samples, bp, b == 0, final_shade);
         }
     }
+}
+
+// One batch of `kb` iterations starting at partition index `first_k`.
+int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
+{
+    const uint32_t depth = r->cfg.max_depth;
+    const size_t n_pixels = static_cast<size_t>(r->width) * r->height;
+    const size_t n_paths = n_pixels * kb;
+    const uint32_t it_first = static_cast<uint32_t>(r->rank + first_k * r->world);
+    // the set of batch buffers this batch runs in, and its stream
+    const uint32_t lane = r->lanes_in_use == 2u ? (r->next_lane++ & 1u) : 0u;
+    hipStream_t st = lane ? r->stream2 : r->stream;
+    float4 *d_samples = lane ? r->d_samples2 : r->d_samples;
+    uint32_t *d_counts = lane ? r->d_counts2 : r->d_counts;
+    uint32_t &tag = lane ? r->sample_tag2 : r->sample_tag;
+    if (lane && r->ops_pending) {
+        PT_HIP(hipStreamWaitEvent(st, r->ev_ops, 0));
+        r->ops_pending = false;
+    }
+    if (++tag == 0u) tag = 1u;  // 0 is the tag of the cleared buffer
+    pt::launch_set_batch(st, r->d_params + lane, r->cam, it_first, tag);
+
+    // (Replaying these launches as a HIP graph was measured on ROCm 7.2 with one-sample draws at 512^2 ... 1080p:
+    // frame time and draw-to-synchronize latency unchanged to the microsecond, so they are issued one by one.)
+    enqueue_bounces(r, lane, kb, st);
     {
         // sum += samples in batch order: wait for the other set's accumulate, which belongs to the batch before
         if (r->ev_accum_set[lane ^ 1u]) PT_HIP(hipStreamWaitEvent(st, r->ev_accum[lane ^ 1u], 0));
@@ -522,7 +563,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
             Timed t(r, 3, st);
             pt::launch_accumulate(st, shape_for(r, n_pixels), d_samples, r->d_sum, static_cast<uint32_t>(n_pixels), kb, d_counts,
                                   depth, regions_for(r, n_paths, 0, -1, d_counts).n_regions, r->region_pitch, r->d_counters,
-                                  r->d_counters + 12, r->d_counters + 1, r->d_rgba8, it_first, r->world, tag);
+                                  r->d_counters + 12, r->d_counters + 1, r->d_rgba8, r->d_params + lane, r->world);
         }
         if (r->two_lanes) {
             PT_HIP(hipEventRecord(r->ev_accum[lane], st));
@@ -1038,7 +1079,8 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
         if (!ok) return bail(fail(PT_ERR_DEVICE, "hipStreamCreate / hipEventCreate failed"));
     }
     if ((rc = upload_scene(r, scene)) != PT_OK) return bail(rc);
-    if (hipMalloc(&r->d_counters, 14 * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMalloc(&r->d_counters, 14 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(&r->d_params, 2 * sizeof(pt::BatchParams)) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipMalloc failed"));
     if ((rc = alloc_paths(r, cfg.width, cfg.height)) != PT_OK) return bail(rc);
     r->cam.tan_half_fov = tan_half_fov(cfg.fov_y_degrees);
@@ -1068,7 +1110,7 @@ void pt_destroy(pt_renderer *r)
     for (hipEvent_t e : {r->ev_accum[0], r->ev_accum[1], r->ev_ops})
         if (e) (void)hipEventDestroy(e);
     if (r->stream2) (void)hipStreamDestroy(r->stream2);
-    void *bufs[] = {r->d_nodes, r->d_tris, r->d_shade, r->d_materials, r->d_lights, r->d_counters};
+    void *bufs[] = {r->d_nodes, r->d_tris, r->d_shade, r->d_materials, r->d_lights, r->d_counters, r->d_params};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (r->stream) (void)hipStreamDestroy(r->stream);
@@ -1363,7 +1405,8 @@ int read_primary(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, flo
     if (dirs) PT_TRY(hipMalloc(&d_dirs, 3 * n * sizeof(float)));
     if (normals) PT_TRY(hipMalloc(&d_normals, 3 * n * sizeof(float)));
     const pt::LaunchShape g = shape_for(r, n);
-    pt::launch_raygen(r->stream, g, r->view, r->cam, iteration, 1, 1, r->q[0], r->d_counts, r->region_size);
+    pt::launch_set_batch(r->stream, r->d_params, r->cam, iteration, 0u);
+    pt::launch_raygen(r->stream, g, r->view, r->d_params, 1, 1, r->q[0], r->d_counts, region_size_for(r, n));
     pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0],
                       pt::ExtendOutput{true, r->d_hits, nullptr, false, false, r->exact_readbacks},
                       pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
@@ -1424,7 +1467,7 @@ int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float 
         PT_TRY(hipMemcpyAsync(d_o, origins + 3 * off, 3 * c * sizeof(float), hipMemcpyHostToDevice, r->stream));
         PT_TRY(hipMemcpyAsync(d_d, dirs + 3 * off, 3 * c * sizeof(float), hipMemcpyHostToDevice, r->stream));
         const pt::LaunchShape g = shape_for(r, c);
-        pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], r->d_counts, r->region_size);
+        pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], r->d_counts, region_size_for(r, c));
         pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, c, 0, -1), r->q[0],
                           pt::ExtendOutput{false, r->d_hits, nullptr, false, false, r->exact_readbacks},
                           pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
