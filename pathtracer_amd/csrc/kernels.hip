@@ -28,13 +28,9 @@ namespace {
 constexpr int kBlock = 256;
 // Experiment knobs of the traversal kernel: threads per block (the block shares
 // one LDS copy of the scene) and the type of a stack entry.
-#ifndef PT_EXT_BLOCK
-#define PT_EXT_BLOCK 256
-#endif
 #ifndef PT_STACK_T
 #define PT_STACK_T int
 #endif
-constexpr int kExtBlock = PT_EXT_BLOCK;
 using StackT = PT_STACK_T;
 static_assert(sizeof(StackT) == 4, "a stack entry holds a child code or the end marker, 32 bits");
 // Minimum waves per SIMD the register allocator must leave room for (second
@@ -393,6 +389,10 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 // it reaches a leaf or runs out of nodes, (B) the lanes standing on a leaf
 // test its triangles.
 //
+// BLOCK: threads per block.  The block shares one LDS copy of the scene, and a CU holds 16 waves of this kernel
+// either way: as four blocks of 256 threads, each with a copy that has to fit in 40 KB with its stacks, or as
+// one block of 1024 threads with the whole 160 KB to itself -- which is what keeps a scene of a thousand
+// triangles (Veggie.obj: 810 nodes) entirely in LDS (+36 % paths/s over caching the top of its tree).
 // SCENE_LDS: 0 = nodes and triangles are read from global memory (L1/L2);
 // 1 = the block keeps a copy of the first n_lds_nodes nodes in LDS (the host
 // numbers the top of the tree breadth-first, so any prefix is the part every
@@ -406,8 +406,8 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 // that escapes or sits on the last allowed segment adds nothing -- and appends
 // the remaining surface hits, compacted per region with ballot + prefix rank,
 // to the hit list the shade kernel consumes: (t, triangle, slot in region).
-template <bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER, bool USE_LT>
-__global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
+template <int BLOCK, bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER, bool USE_LT>
+__global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
                                                         float4 *__restrict__ hit_list, float4 *__restrict__ samples,
                                                         uint32_t last_segment,
                                                         TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
@@ -421,20 +421,20 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
     // the last lane unused); the host asks for it when the part of the scene kept in LDS still fits that way.
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     extern __shared__ float4 lds[];
-    StackT *stack = reinterpret_cast<StackT *>(lds);           // stack_entries * kExtBlock entries, [entry][lane]
-    float4 *lds_nodes = lds + (stack_entries * kExtBlock * sizeof(StackT)) / 16;  // the first n_lds_nodes nodes
+    StackT *stack = reinterpret_cast<StackT *>(lds);           // stack_entries * BLOCK entries, [entry][lane]
+    float4 *lds_nodes = lds + (stack_entries * BLOCK * sizeof(StackT)) / 16;  // the first n_lds_nodes nodes
     float4 *lds_tris = lds_nodes + lds_stride * static_cast<size_t>(n_lds_nodes);
     const uint32_t lds_rec_bytes = 16u * lds_stride;  // all triangles (SCENE_LDS == 2)
     const uint32_t tid = threadIdx.x;
     if (SCENE_LDS >= 1) {
-        for (uint32_t i = tid; i < 4u * n_lds_nodes; i += kExtBlock)
+        for (uint32_t i = tid; i < 4u * n_lds_nodes; i += BLOCK)
             lds_nodes[(i >> 2) * lds_stride + (i & 3u)] = sc.nodes[i];
         if (SCENE_LDS == 2)
-            for (uint32_t i = tid; i < 4u * sc.n_triangles; i += kExtBlock)
+            for (uint32_t i = tid; i < 4u * sc.n_triangles; i += BLOCK)
                 lds_tris[(i >> 2) * lds_stride + (i & 3u)] = sc.triangles[i];
         __syncthreads();
     }
-    const uint32_t n_waves = gridDim.x * (kExtBlock / 64);
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     unsigned long long my_nodes = 0, my_tris = 0;
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-level diagnostics (COUNT only)
     const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
     // previous region are still in flight (at most two regions at a time, told
     // apart by one parity bit per lane), so only the very end of the kernel
     // runs with thinning lanes.
-    uint32_t k = blockIdx.x * (kExtBlock / 64) + (tid >> 6);  // next turn of this wave
+    uint32_t k = blockIdx.x * (BLOCK / 64) + (tid >> 6);  // next turn of this wave
     uint32_t cur_r = 0, cur_n = 0, cur_base = 0, cur_next = 0, cur_h0 = 0, cur_h1 = 0;  // region being handed out
     uint32_t prv_r = 0, prv_base = 0, prv_h0 = 0, prv_h1 = 0;                           // region before it
     bool cur_valid = false, prv_valid = false;
@@ -579,13 +579,13 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                     const bool second_first = hit1 && !(hit0 && tn0 <= tn1);
                     const int near_c = second_first ? c1 : c0, far_c = second_first ? c0 : c1;
                     if (hit0 && hit1) {
-                        stack[sp * kExtBlock + tid] = static_cast<StackT>(far_c);
+                        stack[sp * BLOCK + tid] = static_cast<StackT>(far_c);
                         ++sp;
                     }
                     node = near_c;
                     if (!(hit0 || hit1)) {
                         --sp;
-                        node = stack[sp * kExtBlock + tid];
+                        node = stack[sp * BLOCK + tid];
                     }
                 }
             }
@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(kExtBlock, PT_EXTEND_WAVES) k_extend_bvh(Scene
                 }
                 if (COUNT) my_tris += cnt;
                 --sp;
-                node = stack[sp * kExtBlock + tid];
+                node = stack[sp * BLOCK + tid];
             }
 
             // ---- finished rays: lights, result, lane becomes idle
@@ -1453,10 +1453,13 @@ void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, const B
 }
 
 namespace {
-// Dynamic LDS of the traversal kernel: the per-lane stacks, then as much of the scene as a block may hold
-// while four blocks (16 waves) still fit on a CU: all nodes and triangles (mode 2), else all nodes (3), else
-// the top of the tree (1), else nothing (0).
+// Dynamic LDS of the traversal kernel: the per-lane stacks, then as much of the scene as the block may hold.
+// Four blocks of 256 threads per CU with 40 KB each, or one block of 1024 threads with 160 KB (16 waves per CU
+// either way; measured: 3 waves per SIMD is 27 % slower).  In order of preference: all nodes and triangles
+// (mode 2) in small blocks, the same in a large block, all nodes (mode 3) in small blocks, in a large block,
+// else small blocks with the top of the tree (1) or nothing (0).
 struct LdsPlan {
+    int block;  // threads per block: 256 or 1024
     int mode;
     uint32_t n_lds_nodes;
     uint32_t stride;  // 16-byte lanes per record in LDS: 5 (spread over the banks) when everything wanted still fits, else 4
@@ -1464,36 +1467,76 @@ struct LdsPlan {
 };
 LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds)
 {
-    static const size_t budget = [] {
+    static const size_t budget_small = [] {
         const char *e = pt::tuning_env("PT_LDS_BUDGET_KB");  // tuning experiments only
         return static_cast<size_t>(e ? std::atoi(e) : 40) * 1024;
     }();
-    const size_t stack_bytes = static_cast<size_t>(stack_entries) * kExtBlock * sizeof(StackT);
-    LdsPlan p{0, 0, 4, 0};
-    // first with records spread over the banks (80 bytes each), then packed (64): the whole scene, else all
-    // nodes; a cached top of the tree is always packed (there capacity counts for more than conflicts)
-    for (uint32_t stride : {5u, 4u}) {
-        const size_t record = 16 * stride;
-        const size_t node_bytes = static_cast<size_t>(n_nodes) * record, tri_bytes = static_cast<size_t>(scene.n_triangles) * record;
-        if (scene_in_lds && stack_bytes + node_bytes + tri_bytes <= budget) {
-            p = LdsPlan{2, n_nodes, stride, stack_bytes + node_bytes + tri_bytes};
-            return p;
+    static const int only_block = [] {
+        const char *e = pt::tuning_env("PT_EXT_BLOCK");  // tuning experiments only: 256 or 1024
+        return e ? std::atoi(e) : 0;
+    }();
+    constexpr size_t budget_large = 160 * 1024;
+    auto stack_bytes = [&](int block) { return static_cast<size_t>(stack_entries) * block * sizeof(StackT); };
+    // mode 2 then mode 3; within a mode small blocks before the large one, records spread over the banks
+    // (80 bytes) before packed ones (64)
+    for (int mode : {2, 3})
+        for (int block : {256, 1024}) {
+            if (only_block && block != only_block) continue;
+            const size_t budget = block == 256 ? budget_small : budget_large;
+            for (uint32_t stride : {5u, 4u}) {
+                const size_t record = 16 * stride;
+                const size_t bytes = stack_bytes(block) + static_cast<size_t>(n_nodes) * record +
+                                     (mode == 2 ? static_cast<size_t>(scene.n_triangles) * record : 0);
+                if (scene_in_lds && bytes <= budget) return LdsPlan{block, mode, n_nodes, stride, bytes};
+            }
         }
-    }
-    for (uint32_t stride : {5u, 4u}) {
-        const size_t record = 16 * stride;
-        const size_t node_bytes = static_cast<size_t>(n_nodes) * record;
-        if (scene_in_lds && stack_bytes + node_bytes <= budget) {
-            p = LdsPlan{3, n_nodes, stride, stack_bytes + node_bytes};
-            return p;
-        }
-    }
-    if (scene_in_lds && stack_bytes + 64 * 64 <= budget) {
+    // The tree does not fit: its top in LDS (packed records: here capacity counts for more than conflicts), the
+    // rest from memory.  A large block caches four times as many nodes as a small one; it is chosen when that is
+    // a good part of the tree (at least a quarter) -- for a tree of millions of nodes a longer prefix changes nothing.
+    static const int top_share = [] {
+        const char *e = pt::tuning_env("PT_TOP_SHARE");  // tuning experiments only
+        return e ? std::atoi(e) : 4;
+    }();
+    const size_t cap_large = stack_bytes(1024) + 64 * 64 <= budget_large ? (budget_large - stack_bytes(1024)) / 64 : 0;
+    const int block = (scene_in_lds && only_block != 256 && cap_large * top_share >= n_nodes) || only_block == 1024 ? 1024 : 256;
+    const size_t budget = block == 256 ? budget_small : budget_large;
+    LdsPlan p{block, 0, 0, 4, 0};
+    if (scene_in_lds && stack_bytes(block) + 64 * 64 <= budget) {
         p.mode = 1;
-        p.n_lds_nodes = static_cast<uint32_t>((budget - stack_bytes) / 64);
+        p.n_lds_nodes = static_cast<uint32_t>(std::min<size_t>((budget - stack_bytes(block)) / 64, n_nodes));
+    } else {
+        p.block = 256;
     }
-    p.bytes = stack_bytes + static_cast<size_t>(p.n_lds_nodes) * 64;
+    p.bytes = stack_bytes(p.block) + static_cast<size_t>(p.n_lds_nodes) * 64;
     return p;
+}
+
+// The instantiation of the traversal kernel for a plan and a set of switches, as a generic function pointer.
+using ExtendKernel = void (*)(SceneView, Regions, PathQueue, float4 *, float4 *, uint32_t, TraversalCounters, uint32_t, uint32_t,
+                              uint32_t, uint32_t, uint32_t, const BatchParams *, uint32_t);
+template <int BLOCK, int L>
+ExtendKernel extend_kernel_for(bool counting, bool exact, bool render, bool use_lt)
+{
+    if (exact && render && use_lt) return k_extend_bvh<BLOCK, false, true, L, true, true>;
+    if (exact && render) return k_extend_bvh<BLOCK, false, true, L, true, false>;
+    if (exact) return k_extend_bvh<BLOCK, false, true, L, false, false>;
+    if (!render) return k_extend_bvh<BLOCK, false, false, L, false, false>;
+    if (counting && use_lt) return k_extend_bvh<BLOCK, true, false, L, true, true>;
+    if (counting) return k_extend_bvh<BLOCK, true, false, L, true, false>;
+    if (use_lt) return k_extend_bvh<BLOCK, false, false, L, true, true>;
+    return k_extend_bvh<BLOCK, false, false, L, true, false>;
+}
+ExtendKernel extend_kernel(const LdsPlan &plan, bool counting, bool exact, bool render, bool use_lt)
+{
+    if (plan.block == 1024) {  // large blocks exist for the modes that keep something in LDS
+        if (plan.mode == 2) return extend_kernel_for<1024, 2>(counting, exact, render, use_lt);
+        if (plan.mode == 3) return extend_kernel_for<1024, 3>(counting, exact, render, use_lt);
+        return extend_kernel_for<1024, 1>(counting, exact, render, use_lt);
+    }
+    if (plan.mode == 2) return extend_kernel_for<256, 2>(counting, exact, render, use_lt);
+    if (plan.mode == 3) return extend_kernel_for<256, 3>(counting, exact, render, use_lt);
+    if (plan.mode == 1) return extend_kernel_for<256, 1>(counting, exact, render, use_lt);
+    return extend_kernel_for<256, 0>(counting, exact, render, use_lt);
 }
 }  // namespace
 
@@ -1501,23 +1544,10 @@ uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t 
                                bool scene_in_lds)
 {
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds);
-    const bool lt = scene.n_lights == 1u;
-    int per_cu = 0;
-#define PT_OCC(L)                                                                                               \
-    per_cu = blocks_per_cu(lt ? reinterpret_cast<const void *>(k_extend_bvh<false, false, L, true, true>)      \
-                              : reinterpret_cast<const void *>(k_extend_bvh<false, false, L, true, false>),    \
-                           kExtBlock, plan.bytes)
-    if (plan.mode == 2)
-        PT_OCC(2);
-    else if (plan.mode == 3)
-        PT_OCC(3);
-    else if (plan.mode == 1)
-        PT_OCC(1);
-    else
-        PT_OCC(0);
-#undef PT_OCC
+    int per_cu = blocks_per_cu(reinterpret_cast<const void *>(extend_kernel(plan, false, false, true, scene.n_lights == 1u)),
+                               plan.block, plan.bytes);
     if (per_cu < 1) per_cu = 1;
-    return n_cus * static_cast<uint32_t>(per_cu) * (kExtBlock / 64);
+    return n_cus * static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(plan.block / 64);
 }
 
 void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
@@ -1550,48 +1580,12 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     static const bool no_lt = pt::tuning_env("PT_NO_LT") != nullptr;  // tuning experiments only
     const bool use_lt = out.light_distance_in_queue && scene.n_lights == 1u && !no_lt && render;
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds);
-    const int lds_mode = plan.mode;
-    const uint32_t n_lds_nodes = plan.n_lds_nodes;
     const uint32_t refill_at = refill_env ? static_cast<uint32_t>(refill_env)
-                                          : ((lds_mode == 0 || (lds_mode == 1 && n_lds_nodes < n_nodes / 8u)) ? 32u : 16u);
-    const size_t lds_bytes = plan.bytes;
-#define PT_LAUNCH_EXTEND2(C, E, L, R, T)                                                                           \
-    do {                                                                                                          \
-        hipLaunchKernelGGL((k_extend_bvh<C, E, L, R, T>),                                                         \
-                           dim3(resident_grid(k_extend_bvh<C, E, L, R, T>, lds_bytes, g, kExtBlock, "PT_EXT_PER_CU")), \
-                           dim3(kExtBlock), lds_bytes, s, scene, regions, q, out.hit_list, out.samples,            \
-                           last, tc, n_nodes, refill_at, stack_entries, n_lds_nodes, plan.stride, out.params,   \
-                           primary);            \
-    } while (0)
-#define PT_LAUNCH_EXTEND1(L)                                                                                       \
-    do {                                                                                                          \
-        if (exact_parallel && render && use_lt)                                                                   \
-            PT_LAUNCH_EXTEND2(false, true, L, true, true);                                                        \
-        else if (exact_parallel && render)                                                                        \
-            PT_LAUNCH_EXTEND2(false, true, L, true, false);                                                       \
-        else if (exact_parallel)                                                                                  \
-            PT_LAUNCH_EXTEND2(false, true, L, false, false);                                                      \
-        else if (!render)                                                                                         \
-            PT_LAUNCH_EXTEND2(false, false, L, false, false);                                                     \
-        else if (counting && use_lt)                                                                              \
-            PT_LAUNCH_EXTEND2(true, false, L, true, true);                                                        \
-        else if (counting)                                                                                        \
-            PT_LAUNCH_EXTEND2(true, false, L, true, false);                                                       \
-        else if (use_lt)                                                                                          \
-            PT_LAUNCH_EXTEND2(false, false, L, true, true);                                                       \
-        else                                                                                                      \
-            PT_LAUNCH_EXTEND2(false, false, L, true, false);                                                      \
-    } while (0)
-    if (lds_mode == 2)
-        PT_LAUNCH_EXTEND1(2);
-    else if (lds_mode == 3)
-        PT_LAUNCH_EXTEND1(3);
-    else if (lds_mode == 1)
-        PT_LAUNCH_EXTEND1(1);
-    else
-        PT_LAUNCH_EXTEND1(0);
-#undef PT_LAUNCH_EXTEND2
-#undef PT_LAUNCH_EXTEND1
+                                          : ((plan.mode == 0 || (plan.mode == 1 && plan.n_lds_nodes < n_nodes / 8u)) ? 32u : 16u);
+    const ExtendKernel kernel = extend_kernel(plan, counting, exact_parallel, render, use_lt);
+    hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block, "PT_EXT_PER_CU")), dim3(plan.block), plan.bytes, s,
+                       scene, regions, q, out.hit_list, out.samples, last, tc, n_nodes, refill_at, stack_entries, plan.n_lds_nodes,
+                       plan.stride, out.params, primary);
 }
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
