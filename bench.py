@@ -321,8 +321,8 @@ def main():
         if os.path.exists(pmc_file):
             allk = json.load(open(pmc_file))
             for name, m in allk.items():
-                # the render-loop instantiation: <COUNT, EXACT, SCENE_LDS, RENDER, USE_LT> = no counters, no exact pass, render
-                short = "extend" if re.fullmatch(r"k_extend_bvh<false, false, \d, true, (true|false)>", name) else \
+                # the render-loop instantiation: <BLOCK, COUNT, EXACT, SCENE_LDS, RENDER, USE_LT> = no counters, no exact pass, render
+                short = "extend" if re.fullmatch(r"k_extend_bvh<\d+, false, false, \d, true, (true|false)>", name) else \
                     ("shade" if name == "k_shade" else None)
                 if short:
                     pmc[short] = m
