@@ -212,6 +212,25 @@ __device__ __forceinline__ uint32_t region_of(const Regions &rg, uint32_t k)
     return static_cast<uint32_t>((static_cast<unsigned long long>(k) * rg.stride) % rg.n_regions);
 }
 
+// LDS by address.  The traversal kernel keeps LDS addresses (32-bit, as the ds_* instructions take them) in its
+// per-lane state instead of indices, so that following a link costs no arithmetic.
+typedef __attribute__((address_space(3))) char LdsChar;
+typedef int LdsInt2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_address(const void *p)
+{
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const LdsChar *)p));
+}
+template <typename T>
+__device__ __forceinline__ T lds_load(uint32_t address)
+{
+    return *(const __attribute__((address_space(3))) T *)static_cast<uintptr_t>(address);
+}
+template <typename T>
+__device__ __forceinline__ void lds_store(uint32_t address, T value)
+{
+    *(__attribute__((address_space(3))) T *)static_cast<uintptr_t>(address) = value;
+}
+
 struct Hit {
     float t;
     int id;  // original triangle index (| kClassBit for a surface that is not purely diffuse), -1 none
@@ -415,20 +434,52 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
                                                         const BatchParams *__restrict__ bp, uint32_t primary)
 {
     const uint32_t sample_tag = RENDER ? bp->sample_tag : 0u;
-    // lds_stride: 16-byte lanes between consecutive records of the LDS copy of the scene.  4 = packed: the four
+    // lds_stride: 16-byte lanes between consecutive triangle records of the LDS copy of the scene.  4 = packed: the four
     // ds_read_b128 of a 64-byte record all start on banks 0, 16, 32 or 48, so the 16 lanes such a read serves at
     // a time collide four deep on average.  5 spreads consecutive records over all banks (records of 80 bytes,
     // the last lane unused); the host asks for it when the part of the scene kept in LDS still fits that way.
+    //
+    // LDS, from address 0: the nodes, the triangles, the stacks.
+    // When ALL nodes are in LDS (SCENE_LDS >= 2) they are kept in a layout of their own, 80 bytes per node:
+    //   floats 9c + 3a + {0, 1, 2} = (lo, hi, lo) of child c's box on axis a;  ints 18, 19 = the child codes,
+    //   an inner child's code being the byte address of its record in LDS.
+    // A ray reads the pair (entry plane, exit plane) of an axis at float offset 0 when it travels in the positive
+    // direction and at float offset 1 when in the negative one, so the planes arrive in the right order without a
+    // select per plane (12 per node step otherwise), and following a child takes no address arithmetic.
+    // Otherwise (SCENE_LDS == 1: the first n_lds_nodes nodes) the 64-byte records are copied as they are.
+    constexpr bool kNodeAddresses = SCENE_LDS >= 2;
+    constexpr uint32_t kLdsNodeBytes = kNodeAddresses ? 80u : 64u;
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     extern __shared__ float4 lds[];
-    StackT *stack = reinterpret_cast<StackT *>(lds);           // stack_entries * BLOCK entries, [entry][lane]
-    float4 *lds_nodes = lds + (stack_entries * BLOCK * sizeof(StackT)) / 16;  // the first n_lds_nodes nodes
-    float4 *lds_tris = lds_nodes + lds_stride * static_cast<size_t>(n_lds_nodes);
-    const uint32_t lds_rec_bytes = 16u * lds_stride;  // all triangles (SCENE_LDS == 2)
+    char *const lds_bytes = reinterpret_cast<char *>(lds);
+    float4 *lds_nodes = lds;                                                        // the first n_lds_nodes nodes
+    float4 *lds_tris = lds + (kLdsNodeBytes / 16u) * static_cast<size_t>(n_lds_nodes);  // all triangles (SCENE_LDS == 2)
+    const uint32_t lds_rec_bytes = 16u * lds_stride;
     const uint32_t tid = threadIdx.x;
+    // stacks: stack_entries * BLOCK entries, [entry][lane]; a lane's entry e lies at stack0 + e * kStackStep
+    constexpr uint32_t kStackStep = BLOCK * sizeof(StackT);
+    const uint32_t lds_base = lds_address(lds_bytes);
+    const uint32_t stack0 = lds_base + kLdsNodeBytes * n_lds_nodes + (SCENE_LDS == 2 ? lds_rec_bytes * sc.n_triangles : 0u) +
+                            tid * static_cast<uint32_t>(sizeof(StackT));  // LDS address of the lane's entry 0
     if (SCENE_LDS >= 1) {
-        for (uint32_t i = tid; i < 4u * n_lds_nodes; i += BLOCK)
-            lds_nodes[(i >> 2) * lds_stride + (i & 3u)] = sc.nodes[i];
+        if (kNodeAddresses) {
+            for (uint32_t i = tid; i < n_lds_nodes; i += BLOCK) {
+                const float4 n0 = sc.nodes[4 * i], n1 = sc.nodes[4 * i + 1], n2 = sc.nodes[4 * i + 2], n3 = sc.nodes[4 * i + 3];
+                float *w = reinterpret_cast<float *>(lds_bytes + 80u * i);
+                // child 0: lo (n0.x n0.y n0.z) hi (n0.w n1.x n1.y); child 1: lo (n1.z n1.w n2.x) hi (n2.y n2.z n2.w)
+                w[0] = n0.x, w[1] = n0.w, w[2] = n0.x;
+                w[3] = n0.y, w[4] = n1.x, w[5] = n0.y;
+                w[6] = n0.z, w[7] = n1.y, w[8] = n0.z;
+                w[9] = n1.z, w[10] = n2.y, w[11] = n1.z;
+                w[12] = n1.w, w[13] = n2.z, w[14] = n1.w;
+                w[15] = n2.x, w[16] = n2.w, w[17] = n2.x;
+                const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                w[18] = __int_as_float(c0 >= 0 ? static_cast<int>(lds_base) + c0 * 80 : c0);
+                w[19] = __int_as_float(c1 >= 0 ? static_cast<int>(lds_base) + c1 * 80 : c1);
+            }
+        } else {
+            for (uint32_t i = tid; i < 4u * n_lds_nodes; i += BLOCK) lds_nodes[i] = sc.nodes[i];
+        }
         if (SCENE_LDS == 2)
             for (uint32_t i = tid; i < 4u * sc.n_triangles; i += BLOCK)
                 lds_tris[(i >> 2) * lds_stride + (i & 3u)] = sc.triangles[i];
@@ -453,18 +504,21 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
     uint32_t nxt_n = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
     {
         // per-lane ray state
-        // A lane's traversal state is `node` (>= 0: an inner node to test; < 0: a leaf code to test; kFinished:
-        // nothing left) and `sp`, the number of deferred children on its stack.  Entry 0 of every stack holds
-        // kFinished, so the pop that finds nothing deferred yields the finished state without a test.
+        // A lane's traversal state is `node` (>= 0: an inner node to test -- its index, or with kNodeAddresses the
+        // LDS address of its record; < 0: a leaf code to test; kFinished: nothing left) and `sp`, the LDS address
+        // of the first free entry of its stack.  Entry 0 of every stack holds kFinished, so the pop that finds
+        // nothing deferred yields the finished state without a test.
         bool active = false, gen = false;
         uint32_t slot = 0;
         f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
         float ix = 0.f, iy = 0.f, iz = 0.f, cnx = 0.f, cny = 0.f, cnz = 0.f, cfx = 0.f, cfy = 0.f, cfz = 0.f;
         bool negx = false, negy = false, negz = false;
+        uint32_t offx = 0, offy = 0, offz = 0;  // kNodeAddresses: 4 bytes on the axes along which the ray travels backwards
         Hit h{__builtin_inff(), -1};
         float ltv = __uint_as_float(kNoLightBits);  // the word beside the ray: |ltv| = distance to the light or NaN, sign = poisoned path
-        int node = kFinished, sp = 1;
-        stack[tid] = static_cast<StackT>(kFinished);
+        int node = kFinished;
+        uint32_t sp = stack0 + kStackStep;  // LDS address of the lane's first free stack entry
+        lds_store<StackT>(stack0, static_cast<StackT>(kFinished));
 
         for (;;) {
             // ---- hand fresh rays to idle lanes
@@ -519,13 +573,16 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
                         negx = ix < 0.f;
                         negy = iy < 0.f;
                         negz = iz < 0.f;
+                        offx = negx ? 4u : 0u;
+                        offy = negy ? 4u : 0u;
+                        offz = negz ? 4u : 0u;
                         // one-light scenes: the light's distance, known since the ray was made, is the limit
                         // the traversal starts with (a surface beyond the light cannot change the outcome)
                         ltv = (USE_LT || (RENDER && !primary)) ? q.lt[slot] : __uint_as_float(kNoLightBits);
                         h.t = (USE_LT && fabsf(ltv) >= 0.f) ? fabsf(ltv) : __builtin_inff();
                         h.id = -1;
-                        node = 0;
-                        sp = 1;
+                        node = kNodeAddresses ? static_cast<int>(lds_base) : 0;  // the root
+                        sp = stack0 + kStackStep;
                         active = true;
                     }
                 }
@@ -543,6 +600,8 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
             }
 
             // ---- phase A: inner nodes
+            // (the limit does not change while lanes descend; quieting it here keeps that out of the loop)
+            const float t_limit = __builtin_canonicalizef(h.t);
             for (;;) {
                 const bool go = node >= 0;
                 const unsigned long long going = __ballot(go);
@@ -552,40 +611,52 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
                     dg[1] += __popcll(going);
                 }
                 if (go) {
-                    float4 n0, n1, n2, n3;
-                    if (SCENE_LDS >= 2 || (SCENE_LDS == 1 && static_cast<uint32_t>(node) < n_lds_nodes)) {
-                        const float4 *np = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(lds_nodes) + __umul24(static_cast<uint32_t>(node), lds_rec_bytes));
-                        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                    float e0x, x0x, e0y, x0y, e0z, x0z, e1x, x1x, e1y, x1y, e1z, x1z;
+                    int c0, c1;
+                    if (kNodeAddresses) {
+                        const uint32_t nb = static_cast<uint32_t>(node);
+                        const uint32_t px = nb + offx, py = nb + offy, pz = nb + offz;
+                        e0x = lds_load<float>(px), x0x = lds_load<float>(px + 4), e1x = lds_load<float>(px + 36), x1x = lds_load<float>(px + 40);
+                        e0y = lds_load<float>(py + 12), x0y = lds_load<float>(py + 16), e1y = lds_load<float>(py + 48), x1y = lds_load<float>(py + 52);
+                        e0z = lds_load<float>(pz + 24), x0z = lds_load<float>(pz + 28), e1z = lds_load<float>(pz + 60), x1z = lds_load<float>(pz + 64);
+                        const LdsInt2 cc = lds_load<LdsInt2>(nb + 72);
+                        c0 = cc.x, c1 = cc.y;
                     } else {
-                        const float4 *np = sc.nodes + 4 * static_cast<size_t>(node);
-                        n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                        float4 n0, n1, n2, n3;
+                        if (SCENE_LDS == 1 && static_cast<uint32_t>(node) < n_lds_nodes) {
+                            const float4 *np = lds_nodes + 4u * static_cast<uint32_t>(node);
+                            n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                        } else {
+                            const float4 *np = sc.nodes + 4 * static_cast<size_t>(node);
+                            n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                        }
+                        // child 0: lo (n0.x n0.y n0.z) hi (n0.w n1.x n1.y); child 1: lo (n1.z n1.w n2.x) hi (n2.y n2.z n2.w)
+                        e0x = negx ? n0.w : n0.x, x0x = negx ? n0.x : n0.w;
+                        e0y = negy ? n1.x : n0.y, x0y = negy ? n0.y : n1.x;
+                        e0z = negz ? n1.y : n0.z, x0z = negz ? n0.z : n1.y;
+                        e1x = negx ? n2.y : n1.z, x1x = negx ? n1.z : n2.y;
+                        e1y = negy ? n2.z : n1.w, x1y = negy ? n1.w : n2.z;
+                        e1z = negz ? n2.w : n2.x, x1z = negz ? n2.x : n2.w;
+                        c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
                     }
                     if (COUNT) ++my_nodes;
-                    // child 0: lo (n0.x n0.y n0.z) hi (n0.w n1.x n1.y); child 1: lo (n1.z n1.w n2.x) hi (n2.y n2.z n2.w)
-                    const float e0x = negx ? n0.w : n0.x, x0x = negx ? n0.x : n0.w;
-                    const float e0y = negy ? n1.x : n0.y, x0y = negy ? n0.y : n1.x;
-                    const float e0z = negz ? n1.y : n0.z, x0z = negz ? n0.z : n1.y;
-                    const float e1x = negx ? n2.y : n1.z, x1x = negx ? n1.z : n2.y;
-                    const float e1y = negy ? n2.z : n1.w, x1y = negy ? n1.w : n2.z;
-                    const float e1z = negz ? n2.w : n2.x, x1z = negz ? n2.x : n2.w;
                     const float tn0 = fmaxf(fmaxf(fmaf(e0x, ix, cnx), fmaf(e0y, iy, cny)), fmaxf(fmaf(e0z, iz, cnz), 0.f));
-                    const float tf0 = fminf(fminf(fmaf(x0x, ix, cfx), fmaf(x0y, iy, cfy)), fminf(fmaf(x0z, iz, cfz), h.t));
+                    const float tf0 = fminf(fminf(fmaf(x0x, ix, cfx), fmaf(x0y, iy, cfy)), fminf(fmaf(x0z, iz, cfz), t_limit));
                     const float tn1 = fmaxf(fmaxf(fmaf(e1x, ix, cnx), fmaf(e1y, iy, cny)), fmaxf(fmaf(e1z, iz, cnz), 0.f));
-                    const float tf1 = fminf(fminf(fmaf(x1x, ix, cfx), fmaf(x1y, iy, cfy)), fminf(fmaf(x1z, iz, cfz), h.t));
+                    const float tf1 = fminf(fminf(fmaf(x1x, ix, cfx), fmaf(x1y, iy, cfy)), fminf(fmaf(x1z, iz, cfz), t_limit));
                     const bool hit0 = tn0 <= tf0, hit1 = tn1 <= tf1;
-                    const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
                     // The nearer of the children that are hit is visited next, the other one deferred; with no
                     // child hit the lane takes up its last deferred child (or finds the end marker).
                     const bool second_first = hit1 && !(hit0 && tn0 <= tn1);
                     const int near_c = second_first ? c1 : c0, far_c = second_first ? c0 : c1;
                     if (hit0 && hit1) {
-                        stack[sp * BLOCK + tid] = static_cast<StackT>(far_c);
-                        ++sp;
+                        lds_store<StackT>(sp, static_cast<StackT>(far_c));
+                        sp += kStackStep;
                     }
                     node = near_c;
                     if (!(hit0 || hit1)) {
-                        --sp;
-                        node = stack[sp * BLOCK + tid];
+                        sp -= kStackStep;
+                        node = lds_load<StackT>(sp);
                     }
                 }
             }
@@ -610,8 +681,8 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
                         test_triangle<false>(sc.triangles + 4 * static_cast<size_t>(first + j), o, d, h);
                 }
                 if (COUNT) my_tris += cnt;
-                --sp;
-                node = stack[sp * BLOCK + tid];
+                sp -= kStackStep;
+                node = lds_load<StackT>(sp);
             }
 
             // ---- finished rays: lights, result, lane becomes idle
@@ -1453,7 +1524,7 @@ void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, const B
 }
 
 namespace {
-// Dynamic LDS of the traversal kernel: the per-lane stacks, then as much of the scene as the block may hold.
+// Dynamic LDS of the traversal kernel: as much of the scene as the block may hold, then the per-lane stacks.
 // Four blocks of 256 threads per CU with 40 KB each, or one block of 1024 threads with 160 KB (16 waves per CU
 // either way; measured: 3 waves per SIMD is 27 % slower).  In order of preference: all nodes and triangles
 // (mode 2) in small blocks, the same in a large block, all nodes (mode 3) in small blocks, in a large block,
@@ -1462,7 +1533,7 @@ struct LdsPlan {
     int block;  // threads per block: 256 or 1024
     int mode;
     uint32_t n_lds_nodes;
-    uint32_t stride;  // 16-byte lanes per record in LDS: 5 (spread over the banks) when everything wanted still fits, else 4
+    uint32_t stride;  // 16-byte lanes per triangle record in LDS: 5 (spread over the banks) when everything wanted still fits, else 4
     size_t bytes;
 };
 LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds)
@@ -1477,17 +1548,18 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
     }();
     constexpr size_t budget_large = 160 * 1024;
     auto stack_bytes = [&](int block) { return static_cast<size_t>(stack_entries) * block * sizeof(StackT); };
-    // mode 2 then mode 3; within a mode small blocks before the large one, records spread over the banks
-    // (80 bytes) before packed ones (64)
+    // mode 2 then mode 3; within a mode small blocks before the large one, triangle records spread over the
+    // banks (80 bytes) before packed ones (64).  With all nodes in LDS a node takes 80 bytes (the kernel's own
+    // layout of them); inner-child codes are LDS addresses there, which keeps the nodes below 2^31 by far.
     for (int mode : {2, 3})
         for (int block : {256, 1024}) {
             if (only_block && block != only_block) continue;
             const size_t budget = block == 256 ? budget_small : budget_large;
             for (uint32_t stride : {5u, 4u}) {
-                const size_t record = 16 * stride;
-                const size_t bytes = stack_bytes(block) + static_cast<size_t>(n_nodes) * record +
-                                     (mode == 2 ? static_cast<size_t>(scene.n_triangles) * record : 0);
+                const size_t bytes = stack_bytes(block) + static_cast<size_t>(n_nodes) * 80 +
+                                     (mode == 2 ? static_cast<size_t>(scene.n_triangles) * 16 * stride : 0);
                 if (scene_in_lds && bytes <= budget) return LdsPlan{block, mode, n_nodes, stride, bytes};
+                if (mode == 3) break;  // no triangles in LDS: the stride changes nothing
             }
         }
     // The tree does not fit: its top in LDS (packed records: here capacity counts for more than conflicts), the

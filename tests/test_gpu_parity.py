@@ -252,7 +252,7 @@ def test_sample_surface_matches_oracle(pt, ob):
     r = _renderer(pt, "Box", 16, 16)
     wi, pdf, f, flags, so = r.sample_surface(mats, nrm, wo, xi, seeds)
     r.close()
-    n_lobe_mismatch = n_bad = n_checked = 0
+    n_lobe_mismatch = n_bad = n_tight = n_checked = 0
     for i in range(n):
         owi, opdf, of, early, oseed = ob.sample_surface(mats[i], nrm[i], wo[i], xi[i], seeds[i])
         assert np.array_equal(oseed, so[i]), "RNG consumption differs"
@@ -267,11 +267,18 @@ def test_sample_surface_matches_oracle(pt, ob):
         ok = (np.allclose(wi[i], owi, atol=2e-4, rtol=2e-3) and np.isclose(pdf[i], opdf, rtol=2e-3, atol=1e-6) and
               np.allclose(f[i], of, rtol=2e-3, atol=1e-6))
         n_bad += 0 if ok else 1
-    print(f"BSDF samples outside tolerance: {n_bad} of {n_checked}; lobe mismatches {n_lobe_mismatch}")
+        # the same at a tenth of the tolerance: what the kernel's own operation order costs (pow5 by
+        # multiplication, a reciprocal reused where the shader divides twice) shows up here
+        tight = (np.allclose(wi[i], owi, atol=2e-5, rtol=2e-4) and np.isclose(pdf[i], opdf, rtol=2e-4, atol=1e-6) and
+                 np.allclose(f[i], of, rtol=2e-4, atol=1e-6))
+        n_tight += 0 if tight else 1
+    print(f"BSDF samples outside rtol 2e-3: {n_bad} of {n_checked}; outside rtol 2e-4: {n_tight}; "
+          f"lobe mismatches {n_lobe_mismatch}")
     assert n_checked > 0.8 * n
     assert n_lobe_mismatch <= n * 2e-4
     # Ill-conditioned samples (grazing microfacet normals, near-TIR refraction) amplify ulp differences.
     assert n_bad <= n * 2e-3, f"{n_bad} of {n_checked} BSDF samples outside tolerance"
+    assert n_tight <= n * 2e-2, f"{n_tight} of {n_checked} BSDF samples outside a tenth of the tolerance"
 
 
 def test_sample_surface_degenerate_frames(pt, ob):
