@@ -246,11 +246,16 @@ def main():
     device = local_rank if distributed else 0
 
     reducer = None
-    if distributed and rehearsal:
+    if distributed:
         import torch
 
-        class HostReduce:  # rehearsal only
-            kind = "gloo on the host (rehearsal)"
+        class HostReduce:
+            """The sums through host memory and gloo: the rehearsal's reduce, and the fall-back when the library's
+            RCCL communicator cannot be made on this machine (the line then says so in config.reduce)."""
+            host_total = True
+
+            def __init__(self, kind):
+                self.kind, self.total = kind, None
 
             def __call__(self, r):
                 t = torch.from_numpy(r.read_sum())
@@ -260,9 +265,24 @@ def main():
             def close(self):
                 pass
 
-        reducer = HostReduce()
-    elif distributed:
-        reducer = Reducer(pt, dist, rank, world, device)
+        if rehearsal:
+            reducer = HostReduce("gloo on the host (rehearsal)")
+        else:
+            why = ""
+            try:
+                reducer = Reducer(pt, dist, rank, world, device)
+            except Exception as e:  # noqa: BLE001 -- whatever it is, the ranks must agree on what to do next
+                why = f"{type(e).__name__}: {e}"
+            ok = torch.tensor([1 if reducer is not None else 0], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if reducer is not None:
+                    reducer.close()
+                reasons = [None] * world
+                dist.all_gather_object(reasons, why)
+                why = next((w for w in reasons if w), "a rank failed")
+                print(f"[bench] rank {rank}: no RCCL communicator ({why}); the sums go through the host", file=sys.stderr)
+                reducer = HostReduce(f"gloo on the host (RCCL communicator failed: {why})")
 
     dt, r = timed_run(pt, dist, args, args.scene, rank, world, device, reducer)
     st = r.stats()
@@ -277,7 +297,7 @@ def main():
         if os.path.exists(fx) and not LATTICE:
             ids, _, _ = r.read_hit_ids(0)
             gates["primary_hit_ids_bit_exact_vs_reference"] = bool(np.array_equal(ids, np.load(fx)["ids"]))
-        s = reducer.total if (reducer is not None and rehearsal) else r.read_sum()
+        s = reducer.total if getattr(reducer, "host_total", False) else r.read_sum()
         gates["samples_per_pixel_root"] = float(s[..., 3].mean())
         gates["image_finite"] = bool(np.isfinite(s).all())
     r.close()

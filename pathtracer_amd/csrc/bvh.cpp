@@ -374,7 +374,7 @@ void build_bvh(const float *vertices, const uint32_t *ids, uint32_t n_triangles,
     double root_area = scene.half_area();
     double cost = 0.0;
     if (root_area > 0.0)
-        for (const TmpNode &n : b.tmp) cost += (n.left >= 0 ? 1.0 : double(n.count)) * n.box.half_area() / root_area;
+        for (const TmpNode &n : b.tmp) cost += (n.left >= 0 ? kTraversalCost : double(n.count)) * n.box.half_area() / root_area;
     out->sah_cost = cost;
     for (int a = 0; a < 3; ++a) {
         out->bounds_lo[a] = scene.lo[a];

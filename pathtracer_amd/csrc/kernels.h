@@ -102,6 +102,9 @@ struct ExtendOutput {
     // First segment of a batch made by launch_raygen: lane p2 (throughput 1, the path's own sample slot) is not
     // stored for it but derived from the queue slot with the camera's slot -> pixel mapping.
     bool primary = false;
+    // Where the traversal kernel keeps the deep ends of its stacks when the tree is read from memory
+    // (extend_stack_overflow_bytes); null: whole stacks in LDS.  One buffer per launch in flight.
+    int *stack_overflow = nullptr;
 };
 
 // stack_entries: entries of the per-lane traversal stack in LDS (>= BVH depth).
@@ -113,7 +116,11 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
 // Waves of the traversal kernel that are resident at once for this scene (the occupancy the LDS-resident part
 // of the scene leaves): the host sizes the regions so that each of them gets the same number of regions.
 uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes,
-                               bool scene_in_lds);
+                               bool scene_in_lds, bool overflow_buffer);
+
+// Bytes of ExtendOutput::stack_overflow this scene's launches want (0: the stacks fit in LDS as they are).
+size_t extend_stack_overflow_bytes(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes,
+                                   bool scene_in_lds);
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
                   const float4 *hit_list, PathQueue out, float4 *samples /* receives the sample of a path whose ray went non-finite */,

@@ -431,7 +431,8 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
                                                         uint32_t last_segment,
                                                         TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
                                                         uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
-                                                        const BatchParams *__restrict__ bp, uint32_t primary)
+                                                        const BatchParams *__restrict__ bp, uint32_t primary,
+                                                        uint32_t lds_stack_entries, int *__restrict__ stack_overflow)
 {
     const uint32_t sample_tag = RENDER ? bp->sample_tag : 0u;
     // lds_stride: 16-byte lanes between consecutive triangle records of the LDS copy of the scene.  4 = packed: the four
@@ -456,8 +457,13 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
     float4 *lds_tris = lds + (kLdsNodeBytes / 16u) * static_cast<size_t>(n_lds_nodes);  // all triangles (SCENE_LDS == 2)
     const uint32_t lds_rec_bytes = 16u * lds_stride;
     const uint32_t tid = threadIdx.x;
-    // stacks: stack_entries * BLOCK entries, [entry][lane]; a lane's entry e lies at stack0 + e * kStackStep
+    // stacks: [entry][lane]; a lane's entry e lies at stack0 + e * kStackStep.
+    // A tree read from memory (SCENE_LDS <= 1) is deep, and its traversal waits for memory, which only more
+    // resident waves hide: such a launch keeps just the first lds_stack_entries entries of every stack in LDS
+    // -- a near-first descent rarely has more children deferred -- and the entries above them in
+    // stack_overflow[entry - lds_stack_entries][lane of the grid], so that more blocks fit on a CU.
     constexpr uint32_t kStackStep = BLOCK * sizeof(StackT);
+    constexpr bool kDeepStack = SCENE_LDS <= 1;
     const uint32_t lds_base = lds_address(lds_bytes);
     const uint32_t stack0 = lds_base + kLdsNodeBytes * n_lds_nodes + (SCENE_LDS == 2 ? lds_rec_bytes * sc.n_triangles : 0u) +
                             tid * static_cast<uint32_t>(sizeof(StackT));  // LDS address of the lane's entry 0
@@ -519,6 +525,20 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
         int node = kFinished;
         uint32_t sp = stack0 + kStackStep;  // LDS address of the lane's first free stack entry
         lds_store<StackT>(stack0, static_cast<StackT>(kFinished));
+        const uint32_t sp_lds_end = stack0 + lds_stack_entries * kStackStep;  // addresses from here on stand for overflow entries
+        const size_t grid_lanes = static_cast<size_t>(gridDim.x) * BLOCK, grid_lane = static_cast<size_t>(blockIdx.x) * BLOCK + tid;
+        auto push = [&](int v) {
+            if (kDeepStack && sp >= sp_lds_end)
+                stack_overflow[((sp - sp_lds_end) / kStackStep) * grid_lanes + grid_lane] = v;
+            else
+                lds_store<StackT>(sp, static_cast<StackT>(v));
+            sp += kStackStep;
+        };
+        auto pop = [&]() -> int {
+            sp -= kStackStep;
+            if (kDeepStack && sp >= sp_lds_end) return stack_overflow[((sp - sp_lds_end) / kStackStep) * grid_lanes + grid_lane];
+            return lds_load<StackT>(sp);
+        };
 
         for (;;) {
             // ---- hand fresh rays to idle lanes
@@ -649,15 +669,9 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
                     // child hit the lane takes up its last deferred child (or finds the end marker).
                     const bool second_first = hit1 && !(hit0 && tn0 <= tn1);
                     const int near_c = second_first ? c1 : c0, far_c = second_first ? c0 : c1;
-                    if (hit0 && hit1) {
-                        lds_store<StackT>(sp, static_cast<StackT>(far_c));
-                        sp += kStackStep;
-                    }
+                    if (hit0 && hit1) push(far_c);
                     node = near_c;
-                    if (!(hit0 || hit1)) {
-                        sp -= kStackStep;
-                        node = lds_load<StackT>(sp);
-                    }
+                    if (!(hit0 || hit1)) node = pop();
                 }
             }
 
@@ -681,8 +695,7 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
                         test_triangle<false>(sc.triangles + 4 * static_cast<size_t>(first + j), o, d, h);
                 }
                 if (COUNT) my_tris += cnt;
-                sp -= kStackStep;
-                node = lds_load<StackT>(sp);
+                node = pop();
             }
 
             // ---- finished rays: lights, result, lane becomes idle
@@ -1529,14 +1542,16 @@ namespace {
 // either way; measured: 3 waves per SIMD is 27 % slower).  In order of preference: all nodes and triangles
 // (mode 2) in small blocks, the same in a large block, all nodes (mode 3) in small blocks, in a large block,
 // else small blocks with the top of the tree (1) or nothing (0).
+constexpr size_t kLdsPerCu = 160 * 1024;
 struct LdsPlan {
     int block;  // threads per block: 256 or 1024
     int mode;
+    uint32_t lds_stack_entries;  // entries of every lane's stack kept in LDS (the rest: the launch's overflow buffer)
     uint32_t n_lds_nodes;
     uint32_t stride;  // 16-byte lanes per triangle record in LDS: 5 (spread over the banks) when everything wanted still fits, else 4
     size_t bytes;
 };
-LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds)
+LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds, bool overflow_buffer)
 {
     static const size_t budget_small = [] {
         const char *e = pt::tuning_env("PT_LDS_BUDGET_KB");  // tuning experiments only
@@ -1546,7 +1561,7 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
         const char *e = pt::tuning_env("PT_EXT_BLOCK");  // tuning experiments only: 256 or 1024
         return e ? std::atoi(e) : 0;
     }();
-    constexpr size_t budget_large = 160 * 1024;
+    constexpr size_t budget_large = kLdsPerCu;
     auto stack_bytes = [&](int block) { return static_cast<size_t>(stack_entries) * block * sizeof(StackT); };
     // mode 2 then mode 3; within a mode small blocks before the large one, triangle records spread over the
     // banks (80 bytes) before packed ones (64).  With all nodes in LDS a node takes 80 bytes (the kernel's own
@@ -1558,12 +1573,37 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
             for (uint32_t stride : {5u, 4u}) {
                 const size_t bytes = stack_bytes(block) + static_cast<size_t>(n_nodes) * 80 +
                                      (mode == 2 ? static_cast<size_t>(scene.n_triangles) * 16 * stride : 0);
-                if (scene_in_lds && bytes <= budget) return LdsPlan{block, mode, n_nodes, stride, bytes};
+                if (scene_in_lds && bytes <= budget) return LdsPlan{block, mode, stack_entries, n_nodes, stride, bytes};
                 if (mode == 3) break;  // no triangles in LDS: the stride changes nothing
             }
         }
-    // The tree does not fit: its top in LDS (packed records: here capacity counts for more than conflicts), the
-    // rest from memory.  A large block caches four times as many nodes as a small one; it is chosen when that is
+    // The tree does not fit: it is read from memory, and the kernel waits for it.  Measured on 10 M triangles
+    // with 1 to 4 blocks of 256 threads per CU: time per launch = 1.56 ms + 8.52 ms / blocks -- waves in flight
+    // are what counts, and LDS is what limits them.  With an overflow buffer for the deep ends of the stacks
+    // (kDeepStack in the kernel) a block keeps kDeepLdsStack entries per lane in LDS and takes a sixth of the
+    // CU's LDS (24 waves per CU; the kernel's registers allow no more), the rest of which caches the top of
+    // the tree.  Without the buffer: whole stacks in LDS, four blocks per CU.
+    static const uint32_t deep_entries = [] {
+        const char *e = pt::tuning_env("PT_DEEP_STACK");  // tuning experiments only
+        return static_cast<uint32_t>(e ? std::max(4, std::atoi(e)) : 16);
+    }();
+    static const size_t deep_budget = [] {
+        const char *e = pt::tuning_env("PT_DEEP_BUDGET_KB");  // tuning experiments only
+        return static_cast<size_t>(e ? std::atoi(e) : 26) * 1024;
+    }();
+    const bool deep = overflow_buffer && stack_entries > deep_entries && only_block != 1024;
+    if (deep) {
+        LdsPlan p{256, 0, deep_entries, 0, 4, 0};
+        const size_t stacks = static_cast<size_t>(deep_entries) * 256 * sizeof(StackT);
+        if (scene_in_lds && stacks + 16 * 64 <= deep_budget) {
+            p.mode = 1;
+            p.n_lds_nodes = static_cast<uint32_t>(std::min<size_t>((deep_budget - stacks) / 64, n_nodes));
+        }
+        p.bytes = stacks + static_cast<size_t>(p.n_lds_nodes) * 64;
+        return p;
+    }
+    // Whole stacks in LDS, the top of the tree beside them (packed records: here capacity counts for more than
+    // conflicts).  A large block caches four times as many nodes as a small one; it is chosen when that is
     // a good part of the tree (at least a quarter) -- for a tree of millions of nodes a longer prefix changes nothing.
     static const int top_share = [] {
         const char *e = pt::tuning_env("PT_TOP_SHARE");  // tuning experiments only
@@ -1572,7 +1612,7 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
     const size_t cap_large = stack_bytes(1024) + 64 * 64 <= budget_large ? (budget_large - stack_bytes(1024)) / 64 : 0;
     const int block = (scene_in_lds && only_block != 256 && cap_large * top_share >= n_nodes) || only_block == 1024 ? 1024 : 256;
     const size_t budget = block == 256 ? budget_small : budget_large;
-    LdsPlan p{block, 0, 0, 4, 0};
+    LdsPlan p{block, 0, stack_entries, 0, 4, 0};
     if (scene_in_lds && stack_bytes(block) + 64 * 64 <= budget) {
         p.mode = 1;
         p.n_lds_nodes = static_cast<uint32_t>(std::min<size_t>((budget - stack_bytes(block)) / 64, n_nodes));
@@ -1585,7 +1625,7 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
 
 // The instantiation of the traversal kernel for a plan and a set of switches, as a generic function pointer.
 using ExtendKernel = void (*)(SceneView, Regions, PathQueue, float4 *, float4 *, uint32_t, TraversalCounters, uint32_t, uint32_t,
-                              uint32_t, uint32_t, uint32_t, const BatchParams *, uint32_t);
+                              uint32_t, uint32_t, uint32_t, const BatchParams *, uint32_t, uint32_t, int *);
 template <int BLOCK, int L>
 ExtendKernel extend_kernel_for(bool counting, bool exact, bool render, bool use_lt)
 {
@@ -1613,13 +1653,23 @@ ExtendKernel extend_kernel(const LdsPlan &plan, bool counting, bool exact, bool 
 }  // namespace
 
 uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes,
-                               bool scene_in_lds)
+                               bool scene_in_lds, bool overflow_buffer)
 {
-    const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds);
+    const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, overflow_buffer);
     int per_cu = blocks_per_cu(reinterpret_cast<const void *>(extend_kernel(plan, false, false, true, scene.n_lights == 1u)),
                                plan.block, plan.bytes);
     if (per_cu < 1) per_cu = 1;
     return n_cus * static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(plan.block / 64);
+}
+
+size_t extend_stack_overflow_bytes(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes,
+                                   bool scene_in_lds)
+{
+    const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, true);
+    if (plan.lds_stack_entries >= stack_entries) return 0;
+    // the largest grid any instantiation for this plan is launched with: what a CU can hold of such blocks
+    const size_t lanes = static_cast<size_t>(n_cus) * (kLdsPerCu / std::max<size_t>(plan.bytes, 1024)) * plan.block;
+    return static_cast<size_t>(stack_entries - plan.lds_stack_entries) * std::max<size_t>(lanes, 1) * sizeof(int);
 }
 
 void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, bool use_bvh,
@@ -1651,13 +1701,13 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     const bool counting = tc.nodes_visited != nullptr;
     static const bool no_lt = pt::tuning_env("PT_NO_LT") != nullptr;  // tuning experiments only
     const bool use_lt = out.light_distance_in_queue && scene.n_lights == 1u && !no_lt && render;
-    const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds);
+    const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, out.stack_overflow != nullptr);
     const uint32_t refill_at = refill_env ? static_cast<uint32_t>(refill_env)
                                           : ((plan.mode == 0 || (plan.mode == 1 && plan.n_lds_nodes < n_nodes / 8u)) ? 32u : 16u);
     const ExtendKernel kernel = extend_kernel(plan, counting, exact_parallel, render, use_lt);
     hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block, "PT_EXT_PER_CU")), dim3(plan.block), plan.bytes, s,
                        scene, regions, q, out.hit_list, out.samples, last, tc, n_nodes, refill_at, stack_entries, plan.n_lds_nodes,
-                       plan.stride, out.params, primary);
+                       plan.stride, out.params, primary, plan.lds_stack_entries, out.stack_overflow);
 }
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,

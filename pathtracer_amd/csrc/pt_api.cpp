@@ -204,6 +204,10 @@ struct pt_renderer {
 
     // per-batch scalars on the device, one block per set of batch buffers (kernels.h, BatchParams)
     pt::BatchParams *d_params = nullptr;
+
+    // the deep ends of the traversal kernel's stacks for a tree that is read from memory (kernels.h,
+    // ExtendOutput::stack_overflow): one buffer per stream, null when the stacks fit in LDS
+    int *d_stack_overflow[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -310,7 +314,8 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         // regions of about 2048 slots amortise the per-region work best, and the two-ended hit list packs its
         // counts into 16 bits each.  size = capacity / (waves * m), rounded up to a multiple of 64.
         const uint32_t waves = r->cfg.use_bvh
-                                   ? pt::extend_resident_waves(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds)
+                                   ? pt::extend_resident_waves(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds,
+                                                              r->d_stack_overflow[0] != nullptr)
                                    : r->n_cus * 32u;
         r->extend_waves = waves;
         size_t m = std::max<size_t>(1, (r->capacity + size_t(waves) * 1024) / (size_t(waves) * 2048));
@@ -520,7 +525,7 @@ void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
         const int hit_row = static_cast<int>(depth + 1 + b);
         {
             Timed t(r, 1, st);
-            pt::ExtendOutput eo{true, d_hits, d_samples, true, last, exact_samples, bp, b == 0};
+            pt::ExtendOutput eo{true, d_hits, d_samples, true, last, exact_samples, bp, b == 0, r->d_stack_overflow[lane]};
             pt::launch_extend(st, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, hit_row, d_counts), in,
                               eo, tc, r->n_nodes, r->scene_in_lds);
         }
@@ -1082,6 +1087,11 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     if (hipMalloc(&r->d_counters, 14 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&r->d_params, 2 * sizeof(pt::BatchParams)) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipMalloc failed"));
+    if (cfg.use_bvh) {
+        const size_t bytes = pt::extend_stack_overflow_bytes(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds);
+        for (int k = 0; k < (r->two_lanes ? 2 : 1) && bytes; ++k)
+            if (hipMalloc(&r->d_stack_overflow[k], bytes) != hipSuccess) return bail(fail(PT_ERR_DEVICE, "hipMalloc failed"));
+    }
     if ((rc = alloc_paths(r, cfg.width, cfg.height)) != PT_OK) return bail(rc);
     r->cam.tan_half_fov = tan_half_fov(cfg.fov_y_degrees);
 
@@ -1110,7 +1120,8 @@ void pt_destroy(pt_renderer *r)
     for (hipEvent_t e : {r->ev_accum[0], r->ev_accum[1], r->ev_ops})
         if (e) (void)hipEventDestroy(e);
     if (r->stream2) (void)hipStreamDestroy(r->stream2);
-    void *bufs[] = {r->d_nodes, r->d_tris, r->d_shade, r->d_materials, r->d_lights, r->d_counters, r->d_params};
+    void *bufs[] = {r->d_nodes, r->d_tris, r->d_shade, r->d_materials, r->d_lights, r->d_counters, r->d_params,
+                    r->d_stack_overflow[0], r->d_stack_overflow[1]};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     if (r->stream) (void)hipStreamDestroy(r->stream);
@@ -1408,7 +1419,7 @@ int read_primary(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, flo
     pt::launch_set_batch(r->stream, r->d_params, r->cam, iteration, 0u);
     pt::launch_raygen(r->stream, g, r->view, r->d_params, 1, 1, r->q[0], r->d_counts, region_size_for(r, n));
     pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0],
-                      pt::ExtendOutput{true, r->d_hits, nullptr, false, false, r->exact_readbacks},
+                      pt::ExtendOutput{true, r->d_hits, nullptr, false, false, r->exact_readbacks, nullptr, false, r->d_stack_overflow[0]},
                       pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
     pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(n), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids, d_t,
                               d_dirs, &r->cam);
@@ -1469,7 +1480,7 @@ int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float 
         const pt::LaunchShape g = shape_for(r, c);
         pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], r->d_counts, region_size_for(r, c));
         pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, c, 0, -1), r->q[0],
-                          pt::ExtendOutput{false, r->d_hits, nullptr, false, false, r->exact_readbacks},
+                          pt::ExtendOutput{false, r->d_hits, nullptr, false, false, r->exact_readbacks, nullptr, false, r->d_stack_overflow[0]},
                           pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
         pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(c), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids,
                                   d_t, nullptr, nullptr);
