@@ -572,15 +572,12 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
                         const float4 a = q.p0[slot], b = q.p1[slot];
                         o = mk(a.x, a.y, a.z);
                         d = mk(a.w, b.x, b.y);
-                        // Reciprocal direction with zero components replaced by +-1e-30
-                        // so that no product below is inf * 0.
-                        const float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
-                        const float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
-                        const float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
-                        // The hardware reciprocal (1 ulp) is enough: the slabs are padded by far more.
-                        ix = __builtin_amdgcn_rcpf(dx);
-                        iy = __builtin_amdgcn_rcpf(dy);
-                        iz = __builtin_amdgcn_rcpf(dz);
+                        // Reciprocal direction, kept within +-1e30 so that no product below is inf * 0 (a zero
+                        // component gives +-inf with its sign, v_med3 brings it back).  The hardware reciprocal
+                        // (1 ulp) is enough: the slabs are padded by far more.
+                        ix = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e30f, 1e30f);
+                        iy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e30f, 1e30f);
+                        iz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e30f, 1e30f);
                         const float pad = 7.62939453125e-6f *
                                           fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), sc.scene_radius));
                         const float mx = pad * fabsf(ix), my_ = pad * fabsf(iy), mz = pad * fabsf(iz);
