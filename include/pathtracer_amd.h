@@ -73,7 +73,11 @@ typedef struct {
                                       plane counts as the hit at t = inf it is there
                                       (frag:404-411).  Such samples add zero to the image
                                       either way; the check costs a scan over all triangles
-                                      per escaping ray                                   */
+                                      per escaping ray;
+                                      bit 3 (for tests): a tree too large for on-chip memory
+                                      is traversed with only 4 entries of each ray's stack
+                                      on chip, so that the overflow buffer, which otherwise
+                                      holds entries 17 and up, is used by most rays       */
     uint32_t emulate_rgba8;        /* 1: beside the float sum, keep the reference's own
                                       accumulator: an 8-bit RGBA texel per pixel updated as
                                       (accum*it + sample)/(it+1) and re-quantised every

@@ -19,6 +19,9 @@ struct SceneView {
     uint32_t n_materials;
     uint32_t n_lights;
     float scene_radius;        // largest |coordinate| of the mesh bounds
+    // Entries of a deep traversal stack (a tree read from memory) kept in LDS; 0 = the default (16).  Tests lower
+    // it so that the overflow buffer is actually used (pt_config.profile bit 3).
+    uint32_t deep_stack_lds_entries = 0;
 };
 
 // One path queue: three 16-byte lanes per path.

@@ -1588,10 +1588,11 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
         const char *e = pt::tuning_env("PT_DEEP_BUDGET_KB");  // tuning experiments only
         return static_cast<size_t>(e ? std::atoi(e) : 26) * 1024;
     }();
-    const bool deep = overflow_buffer && stack_entries > deep_entries && only_block != 1024;
+    const uint32_t lds_entries = scene.deep_stack_lds_entries ? scene.deep_stack_lds_entries : deep_entries;
+    const bool deep = overflow_buffer && stack_entries > lds_entries && only_block != 1024;
     if (deep) {
-        LdsPlan p{256, 0, deep_entries, 0, 4, 0};
-        const size_t stacks = static_cast<size_t>(deep_entries) * 256 * sizeof(StackT);
+        LdsPlan p{256, 0, lds_entries, 0, 4, 0};
+        const size_t stacks = static_cast<size_t>(lds_entries) * 256 * sizeof(StackT);
         if (scene_in_lds && stacks + 16 * 64 <= deep_budget) {
             p.mode = 1;
             p.n_lds_nodes = static_cast<uint32_t>(std::min<size_t>((deep_budget - stacks) / 64, n_nodes));

@@ -1087,6 +1087,7 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     if (hipMalloc(&r->d_counters, 14 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&r->d_params, 2 * sizeof(pt::BatchParams)) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipMalloc failed"));
+    if (cfg.profile & 8u) r->view.deep_stack_lds_entries = 4;  // tests: make deep stacks overflow early
     if (cfg.use_bvh) {
         const size_t bytes = pt::extend_stack_overflow_bytes(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds);
         for (int k = 0; k < (r->two_lanes ? 2 : 1) && bytes; ++k)

@@ -166,9 +166,12 @@ def test_bvh_extend_equals_linear_scan_of_oracle(pt, ob, name):
     assert np.array_equal(t.view(np.uint32)[ok], ot.view(np.uint32)[ok])
 
 
-def test_bvh_extend_on_instanced_lattice(pt, ob):
+@pytest.mark.parametrize("profile", [0, 8])
+def test_bvh_extend_on_instanced_lattice(pt, ob, profile):
     """38 890 triangles, tree depth > 16: a deeper traversal stack, and a node array too large for LDS
-    (the kernel keeps the top of the tree there and reads the rest from global memory)."""
+    (the kernel keeps the top of the tree there and reads the rest from global memory; of each stack the
+    first 16 entries are in LDS and the rest in an overflow buffer -- with profile bit 3 only the first 4,
+    so that nearly every ray goes through the overflow path).  A render must not depend on it either."""
     lat = _scene(pt, "Veggie").instance_lattice(10, 3)
     a = lat.arrays()
     assert lat.bvh_info()["stack_entries"] > 16
@@ -183,13 +186,21 @@ def test_bvh_extend_on_instanced_lattice(pt, ob):
     ot, oid = ob.trace(osc, o, d)
     ok = ~ob.poisoned(osc, o, d)  # see test_bvh_extend_equals_linear_scan_of_oracle
     assert ok[4000:].all()
-    r = pt.Renderer(lat, pt.Camera(resolution=(64, 64)))
+    r = pt.Renderer(lat, pt.Camera(resolution=(64, 64)), profile=profile)
     t, ids = r.trace_rays(o, d)
     st = r.stats()
+    r.draw(3)
+    img = r.read_sum()
     r.close()
     assert st["stack_entries"] > 16 and st["n_nodes"] * 64 > 64 * 1024
     assert np.array_equal(ids[ok], oid[ok])
     assert np.array_equal(t.view(np.uint32)[ok], ot.view(np.uint32)[ok])
+    if profile:
+        r = pt.Renderer(lat, pt.Camera(resolution=(64, 64)))
+        r.draw(3)
+        ref = r.read_sum()
+        r.close()
+        assert np.array_equal(img, ref) and np.isfinite(img).all()
 
 
 def test_bvh_extend_on_the_ten_million_triangle_scene(pt, ob):
@@ -278,7 +289,7 @@ def test_sample_surface_matches_oracle(pt, ob):
     assert n_lobe_mismatch <= n * 2e-4
     # Ill-conditioned samples (grazing microfacet normals, near-TIR refraction) amplify ulp differences.
     assert n_bad <= n * 2e-3, f"{n_bad} of {n_checked} BSDF samples outside tolerance"
-    assert n_tight <= n * 2e-2, f"{n_tight} of {n_checked} BSDF samples outside a tenth of the tolerance"
+    assert n_tight <= n * 1e-3, f"{n_tight} of {n_checked} BSDF samples outside a tenth of the tolerance"  # measured: 7
 
 
 def test_sample_surface_degenerate_frames(pt, ob):
