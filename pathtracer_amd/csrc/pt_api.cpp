@@ -729,7 +729,7 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
     r->bvh_build_ms = now_ms() - t0 - device_upload_ms;
     stage("BVH");
     r->bvh_builder = device_build ? 1u : 0u;
-    r->stack_entries = std::max<uint32_t>(4, (r->bvh_depth + 1u + 3u) & ~3u);  // LDS stack: the end marker + one entry per inner level, in fours
+    r->stack_entries = std::max<uint32_t>(4, r->bvh_depth + 1u);  // traversal stack: the end marker + one entry per inner level
 
     std::vector<pt::ShadeTriangle> shade(device_build ? 0 : T);
     for (uint32_t t = 0; t < static_cast<uint32_t>(shade.size()); ++t) {
@@ -1584,7 +1584,7 @@ int pt_bvh_inspect(const pt_scene_desc *sc, pt_bvh_info *info)
     info->n_triangles = T;
     info->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
     info->depth = bvh.depth;
-    info->stack_entries = std::max<uint32_t>(4, (bvh.depth + 1u + 3u) & ~3u);
+    info->stack_entries = std::max<uint32_t>(4, bvh.depth + 1u);
     info->sah_cost = bvh.sah_cost;
 
     // Walk the tree: boxes must enclose everything below them; leaves must

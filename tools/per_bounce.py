@@ -18,7 +18,7 @@ for r in rows:
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     if "k_raygen" in n:
         seq.append({"extend": [], "shade": [], "raygen": us})
-    elif seq and "k_extend_bvh<false, false" in n:
+    elif seq and ("k_extend_bvh<" in n and ", false, false, " in n):
         seq[-1]["extend"].append(us)
     elif seq and "k_shade" in n and "records" not in n:
         seq[-1]["shade"].append(us)
