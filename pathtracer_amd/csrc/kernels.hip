@@ -216,6 +216,7 @@ __device__ __forceinline__ uint32_t region_of(const Regions &rg, uint32_t k)
 // per-lane state instead of indices, so that following a link costs no arithmetic.
 typedef __attribute__((address_space(3))) char LdsChar;
 typedef int LdsInt2 __attribute__((ext_vector_type(2)));
+typedef float LdsFloat4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t lds_address(const void *p)
 {
     return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const LdsChar *)p));
@@ -441,15 +442,17 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
     // the last lane unused); the host asks for it when the part of the scene kept in LDS still fits that way.
     //
     // LDS, from address 0: the nodes, the triangles, the stacks.
-    // When ALL nodes are in LDS (SCENE_LDS >= 2) they are kept in a layout of their own, 80 bytes per node:
-    //   floats 9c + 3a + {0, 1, 2} = (lo, hi, lo) of child c's box on axis a;  ints 18, 19 = the child codes,
-    //   an inner child's code being the byte address of its record in LDS.
-    // A ray reads the pair (entry plane, exit plane) of an axis at float offset 0 when it travels in the positive
-    // direction and at float offset 1 when in the negative one, so the planes arrive in the right order without a
-    // select per plane (12 per node step otherwise), and following a child takes no address arithmetic.
+    // When ALL nodes are in LDS (SCENE_LDS >= 2) they are kept in a layout of their own, 112 bytes per node:
+    //   floats 8a + {0..3} = (lo0, hi0, lo1, hi1) of the two children's boxes on axis a, floats 8a + {4..7} =
+    //   (hi0, lo0, hi1, lo1);  ints 24, 25 = the child codes, an inner child's code being the LDS address of its record.
+    // A ray reads (entry plane, exit plane) of both children on an axis with one ds_read_b128, from the first
+    // quadruple when it travels in the positive direction and from the second when in the negative one: the
+    // planes arrive in the right order without a select per plane (12 per node step otherwise), in four LDS
+    // instructions per node, and following a child takes no address arithmetic.  (Records of an odd number of
+    // 16-byte lanes also spread over the banks.)
     // Otherwise (SCENE_LDS == 1: the first n_lds_nodes nodes) the 64-byte records are copied as they are.
     constexpr bool kNodeAddresses = SCENE_LDS >= 2;
-    constexpr uint32_t kLdsNodeBytes = kNodeAddresses ? 80u : 64u;
+    constexpr uint32_t kLdsNodeBytes = kNodeAddresses ? 112u : 64u;
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     extern __shared__ float4 lds[];
     char *const lds_bytes = reinterpret_cast<char *>(lds);
@@ -471,17 +474,14 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
         if (kNodeAddresses) {
             for (uint32_t i = tid; i < n_lds_nodes; i += BLOCK) {
                 const float4 n0 = sc.nodes[4 * i], n1 = sc.nodes[4 * i + 1], n2 = sc.nodes[4 * i + 2], n3 = sc.nodes[4 * i + 3];
-                float *w = reinterpret_cast<float *>(lds_bytes + 80u * i);
+                float4 *w = reinterpret_cast<float4 *>(lds_bytes + kLdsNodeBytes * i);
                 // child 0: lo (n0.x n0.y n0.z) hi (n0.w n1.x n1.y); child 1: lo (n1.z n1.w n2.x) hi (n2.y n2.z n2.w)
-                w[0] = n0.x, w[1] = n0.w, w[2] = n0.x;
-                w[3] = n0.y, w[4] = n1.x, w[5] = n0.y;
-                w[6] = n0.z, w[7] = n1.y, w[8] = n0.z;
-                w[9] = n1.z, w[10] = n2.y, w[11] = n1.z;
-                w[12] = n1.w, w[13] = n2.z, w[14] = n1.w;
-                w[15] = n2.x, w[16] = n2.w, w[17] = n2.x;
+                w[0] = make_float4(n0.x, n0.w, n1.z, n2.y), w[1] = make_float4(n0.w, n0.x, n2.y, n1.z);
+                w[2] = make_float4(n0.y, n1.x, n1.w, n2.z), w[3] = make_float4(n1.x, n0.y, n2.z, n1.w);
+                w[4] = make_float4(n0.z, n1.y, n2.x, n2.w), w[5] = make_float4(n1.y, n0.z, n2.w, n2.x);
                 const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                w[18] = __int_as_float(c0 >= 0 ? static_cast<int>(lds_base) + c0 * 80 : c0);
-                w[19] = __int_as_float(c1 >= 0 ? static_cast<int>(lds_base) + c1 * 80 : c1);
+                w[6] = make_float4(__int_as_float(c0 >= 0 ? static_cast<int>(lds_base + kLdsNodeBytes * static_cast<uint32_t>(c0)) : c0),
+                                   __int_as_float(c1 >= 0 ? static_cast<int>(lds_base + kLdsNodeBytes * static_cast<uint32_t>(c1)) : c1), 0.f, 0.f);
             }
         } else {
             for (uint32_t i = tid; i < 4u * n_lds_nodes; i += BLOCK) lds_nodes[i] = sc.nodes[i];
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
         f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
         float ix = 0.f, iy = 0.f, iz = 0.f, cnx = 0.f, cny = 0.f, cnz = 0.f, cfx = 0.f, cfy = 0.f, cfz = 0.f;
         bool negx = false, negy = false, negz = false;
-        uint32_t offx = 0, offy = 0, offz = 0;  // kNodeAddresses: 4 bytes on the axes along which the ray travels backwards
+        uint32_t offx = 0, offy = 0, offz = 0;  // kNodeAddresses: 16 bytes on the axes along which the ray travels backwards
         Hit h{__builtin_inff(), -1};
         float ltv = __uint_as_float(kNoLightBits);  // the word beside the ray: |ltv| = distance to the light or NaN, sign = poisoned path
         int node = kFinished;
@@ -590,9 +590,9 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
                         negx = ix < 0.f;
                         negy = iy < 0.f;
                         negz = iz < 0.f;
-                        offx = negx ? 4u : 0u;
-                        offy = negy ? 4u : 0u;
-                        offz = negz ? 4u : 0u;
+                        offx = negx ? 16u : 0u;
+                        offy = negy ? 16u : 0u;
+                        offz = negz ? 16u : 0u;
                         // one-light scenes: the light's distance, known since the ray was made, is the limit
                         // the traversal starts with (a surface beyond the light cannot change the outcome)
                         ltv = (USE_LT || (RENDER && !primary)) ? q.lt[slot] : __uint_as_float(kNoLightBits);
@@ -632,11 +632,12 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
                     int c0, c1;
                     if (kNodeAddresses) {
                         const uint32_t nb = static_cast<uint32_t>(node);
-                        const uint32_t px = nb + offx, py = nb + offy, pz = nb + offz;
-                        e0x = lds_load<float>(px), x0x = lds_load<float>(px + 4), e1x = lds_load<float>(px + 36), x1x = lds_load<float>(px + 40);
-                        e0y = lds_load<float>(py + 12), x0y = lds_load<float>(py + 16), e1y = lds_load<float>(py + 48), x1y = lds_load<float>(py + 52);
-                        e0z = lds_load<float>(pz + 24), x0z = lds_load<float>(pz + 28), e1z = lds_load<float>(pz + 60), x1z = lds_load<float>(pz + 64);
-                        const LdsInt2 cc = lds_load<LdsInt2>(nb + 72);
+                        const LdsFloat4 ax = lds_load<LdsFloat4>(nb + offx), ay = lds_load<LdsFloat4>(nb + offy + 32u),
+                                        az = lds_load<LdsFloat4>(nb + offz + 64u);
+                        e0x = ax.x, x0x = ax.y, e1x = ax.z, x1x = ax.w;
+                        e0y = ay.x, x0y = ay.y, e1y = ay.z, x1y = ay.w;
+                        e0z = az.x, x0z = az.y, e1z = az.z, x1z = az.w;
+                        const LdsInt2 cc = lds_load<LdsInt2>(nb + 96u);
                         c0 = cc.x, c1 = cc.y;
                     } else {
                         float4 n0, n1, n2, n3;
@@ -1561,14 +1562,14 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
     constexpr size_t budget_large = kLdsPerCu;
     auto stack_bytes = [&](int block) { return static_cast<size_t>(stack_entries) * block * sizeof(StackT); };
     // mode 2 then mode 3; within a mode small blocks before the large one, triangle records spread over the
-    // banks (80 bytes) before packed ones (64).  With all nodes in LDS a node takes 80 bytes (the kernel's own
+    // banks (80 bytes) before packed ones (64).  With all nodes in LDS a node takes 112 bytes (the kernel's own
     // layout of them); inner-child codes are LDS addresses there, which keeps the nodes below 2^31 by far.
     for (int mode : {2, 3})
         for (int block : {256, 1024}) {
             if (only_block && block != only_block) continue;
             const size_t budget = block == 256 ? budget_small : budget_large;
             for (uint32_t stride : {5u, 4u}) {
-                const size_t bytes = stack_bytes(block) + static_cast<size_t>(n_nodes) * 80 +
+                const size_t bytes = stack_bytes(block) + static_cast<size_t>(n_nodes) * 112 +
                                      (mode == 2 ? static_cast<size_t>(scene.n_triangles) * 16 * stride : 0);
                 if (scene_in_lds && bytes <= budget) return LdsPlan{block, mode, stack_entries, n_nodes, stride, bytes};
                 if (mode == 3) break;  // no triangles in LDS: the stride changes nothing
