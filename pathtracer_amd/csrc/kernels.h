@@ -125,6 +125,21 @@ uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t 
 size_t extend_stack_overflow_bytes(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes,
                                    bool scene_in_lds);
 
+// Every bounce of a batch in one launch (k_bounces): the launches launch_extend / launch_shade would make for
+// bounces 0 .. depth-1 of the render loop (no counters, no exact-samples pass), with the same results.
+struct BounceLoop {
+    PathQueue q[2];    // bounce b reads q[b & 1] and writes q[(b + 1) & 1]
+    float4 *hit_list;
+    float4 *samples;
+    uint32_t *counts;  // rows of `pitch` entries: 0..depth rays per region and bounce, depth+1.. hits per region and bounce
+    uint32_t pitch, n_regions, stride, size, depth;
+};
+// Waves of k_bounces resident at once for this scene (as extend_resident_waves for the traversal kernel).
+uint32_t bounces_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds,
+                                bool overflow_buffer);
+void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, const BounceLoop &loop,
+                    const BatchParams *params, uint32_t n_nodes, bool scene_in_lds, int *stack_overflow);
+
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
                   const float4 *hit_list, PathQueue out, float4 *samples /* receives the sample of a path whose ray went non-finite */,
                   const BatchParams *params, bool primary /* as in ExtendOutput */,

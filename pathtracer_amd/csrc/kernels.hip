@@ -426,14 +426,15 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
 // that escapes or sits on the last allowed segment adds nothing -- and appends
 // the remaining surface hits, compacted per region with ballot + prefix rank,
 // to the hit list the shade kernel consumes: (t, triangle, slot in region).
+//
+// The body is a device function so that it can also run inside k_bounces (all bounces of a batch in one launch);
+// fill_lds: copy the scene to LDS first (k_bounces does that once, not per bounce).
 template <int BLOCK, bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER, bool USE_LT>
-__global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
-                                                        float4 *__restrict__ hit_list, float4 *__restrict__ samples,
-                                                        uint32_t last_segment,
-                                                        TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
-                                                        uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
-                                                        const BatchParams *__restrict__ bp, uint32_t primary,
-                                                        uint32_t lds_stack_entries, int *__restrict__ stack_overflow)
+__device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &rg, const PathQueue &q, float4 *hit_list,
+                                            float4 *samples, uint32_t last_segment, const TraversalCounters &tc, uint32_t n_nodes,
+                                            uint32_t refill_at, uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
+                                            const BatchParams *bp, uint32_t primary, uint32_t lds_stack_entries,
+                                            int *stack_overflow, bool fill_lds)
 {
     const uint32_t sample_tag = RENDER ? bp->sample_tag : 0u;
     // lds_stride: 16-byte lanes between consecutive triangle records of the LDS copy of the scene.  4 = packed: the four
@@ -470,7 +471,7 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
     const uint32_t lds_base = lds_address(lds_bytes);
     const uint32_t stack0 = lds_base + kLdsNodeBytes * n_lds_nodes + (SCENE_LDS == 2 ? lds_rec_bytes * sc.n_triangles : 0u) +
                             tid * static_cast<uint32_t>(sizeof(StackT));  // LDS address of the lane's entry 0
-    if (SCENE_LDS >= 1) {
+    if (SCENE_LDS >= 1 && fill_lds) {
         if (kNodeAddresses) {
             for (uint32_t i = tid; i < n_lds_nodes; i += BLOCK) {
                 const float4 n0 = sc.nodes[4 * i], n1 = sc.nodes[4 * i + 1], n2 = sc.nodes[4 * i + 2], n3 = sc.nodes[4 * i + 3];
@@ -759,6 +760,20 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
             atomicMax(tc.diag + 7, dt);
         }
     }
+}
+
+template <int BLOCK, bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER, bool USE_LT>
+__global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
+                                                        float4 *__restrict__ hit_list, float4 *__restrict__ samples,
+                                                        uint32_t last_segment,
+                                                        TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
+                                                        uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
+                                                        const BatchParams *__restrict__ bp, uint32_t primary,
+                                                        uint32_t lds_stack_entries, int *__restrict__ stack_overflow)
+{
+    extend_body<BLOCK, COUNT, EXACT, SCENE_LDS, RENDER, USE_LT>(sc, rg, q, hit_list, samples, last_segment, tc, n_nodes, refill_at,
+                                                                stack_entries, n_lds_nodes, lds_stride, bp, primary,
+                                                                lds_stack_entries, stack_overflow, true);
 }
 
 // ----------------------------------------------------------------- shade
@@ -1134,15 +1149,16 @@ __device__ __forceinline__ f3 interpolated_normal(float4 s0, float4 s1, float4 s
 // simply is not written: its sample slot already holds zero.  final_bounce: the
 // hits are those of the paths' last allowed segment; nothing survives, the BSDF
 // is evaluated only because a non-finite value it produces is the path's sample.
-__global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, Regions rg, PathQueue in,
-                                                   const float4 *__restrict__ hit_list, PathQueue out,
-                                                   float4 *__restrict__ samples, const BatchParams *__restrict__ bp,
-                                                   uint32_t primary, uint32_t final_bounce)
+// (A device function for the same reason as extend_body; BLOCK = threads per block of the launch it runs in.)
+template <int BLOCK>
+__device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &rg, const PathQueue &in, const float4 *hit_list,
+                                           const PathQueue &out, float4 *samples, const BatchParams *bp, uint32_t primary,
+                                           uint32_t final_bounce)
 {
     const uint32_t sample_tag = bp->sample_tag;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    uint32_t k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    uint32_t k = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     uint32_t nxt_r = k < rg.n_regions ? region_of(rg, k) : 0u;
     uint32_t nxt_packed = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
     while (k < rg.n_regions) {
@@ -1263,6 +1279,46 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
         out_n += static_cast<uint32_t>(__popcll(live));
       }
       if (lane == 0) rg.counts_out[r] = out_n;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, Regions rg, PathQueue in,
+                                                   const float4 *__restrict__ hit_list, PathQueue out,
+                                                   float4 *__restrict__ samples, const BatchParams *__restrict__ bp,
+                                                   uint32_t primary, uint32_t final_bounce)
+{
+    shade_body<kBlock>(sc, rg, in, hit_list, out, samples, bp, primary, final_bounce);
+}
+
+// ------------------------------------------------- all bounces in one launch
+
+// raygen's output through every bounce of the batch in ONE launch.  A region's data never leaves its wave: the
+// traversal reads region r of the ray queue and writes region r of the hit list, the shading reads those and
+// writes region r of the other queue, and a wave visits the same regions in both (turns k, k + n_waves, ... of
+// the same grid).  So a wave carries its regions through all bounces with no synchronisation between waves;
+// between two phases it only has to see its own writes (a workgroup-scope fence: its stores have reached the
+// CU's cache, through which it also reads).  Against 2 * depth - 1 launches this removes the start-up and drain
+// of kernels over thinning queues, which is what a small batch -- the reference's one sample per draw -- spends
+// its time on.  Render loop only: no counters, no exact pass.
+template <int BLOCK, int SCENE_LDS, bool USE_LT>
+__global__ void __launch_bounds__(BLOCK, 4) k_bounces(SceneView sc, BounceLoop L, uint32_t n_nodes, uint32_t refill_at,
+                                                      uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
+                                                      const BatchParams *__restrict__ bp, uint32_t lds_stack_entries,
+                                                      int *stack_overflow)
+{
+    const TraversalCounters no_counters{nullptr, nullptr, nullptr};
+    for (uint32_t b = 0; b < L.depth; ++b) {
+        const uint32_t last = b + 1u == L.depth ? 1u : 0u;
+        uint32_t *rays = L.counts + static_cast<size_t>(b) * L.pitch, *hits = L.counts + static_cast<size_t>(L.depth + 1u + b) * L.pitch;
+        const Regions re{rays, hits, L.n_regions, L.stride, L.size};
+        extend_body<BLOCK, false, false, SCENE_LDS, true, USE_LT>(sc, re, L.q[b & 1u], L.hit_list, L.samples, last, no_counters, n_nodes,
+                                                                 refill_at, stack_entries, n_lds_nodes, lds_stride, bp, b == 0u ? 1u : 0u,
+                                                                 lds_stack_entries, stack_overflow, b == 0u);
+        if (last) break;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const Regions rs{hits, L.counts + static_cast<size_t>(b + 1u) * L.pitch, L.n_regions, L.stride, L.size};
+        shade_body<BLOCK>(sc, rs, L.q[b & 1u], L.hit_list, L.q[(b + 1u) & 1u], L.samples, bp, b == 0u ? 1u : 0u, 0u);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 }
 
@@ -1707,6 +1763,47 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block, "PT_EXT_PER_CU")), dim3(plan.block), plan.bytes, s,
                        scene, regions, q, out.hit_list, out.samples, last, tc, n_nodes, refill_at, stack_entries, plan.n_lds_nodes,
                        plan.stride, out.params, primary, plan.lds_stack_entries, out.stack_overflow);
+}
+
+namespace {
+using BouncesKernel = void (*)(SceneView, BounceLoop, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const BatchParams *, uint32_t, int *);
+template <int BLOCK, int L>
+BouncesKernel bounces_kernel_for(bool use_lt)
+{
+    return use_lt ? k_bounces<BLOCK, L, true> : k_bounces<BLOCK, L, false>;
+}
+BouncesKernel bounces_kernel(const LdsPlan &plan, bool use_lt)
+{
+    if (plan.block == 1024) {
+        if (plan.mode == 2) return bounces_kernel_for<1024, 2>(use_lt);
+        if (plan.mode == 3) return bounces_kernel_for<1024, 3>(use_lt);
+        return bounces_kernel_for<1024, 1>(use_lt);
+    }
+    if (plan.mode == 2) return bounces_kernel_for<256, 2>(use_lt);
+    if (plan.mode == 3) return bounces_kernel_for<256, 3>(use_lt);
+    if (plan.mode == 1) return bounces_kernel_for<256, 1>(use_lt);
+    return bounces_kernel_for<256, 0>(use_lt);
+}
+}  // namespace
+
+uint32_t bounces_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds,
+                                bool overflow_buffer)
+{
+    const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, overflow_buffer);
+    int per_cu = blocks_per_cu(reinterpret_cast<const void *>(bounces_kernel(plan, scene.n_lights == 1u)), plan.block, plan.bytes);
+    if (per_cu < 1) per_cu = 1;
+    return n_cus * static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(plan.block / 64);
+}
+
+void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, const BounceLoop &loop,
+                    const BatchParams *params, uint32_t n_nodes, bool scene_in_lds, int *stack_overflow)
+{
+    const bool use_lt = scene.n_lights == 1u;  // raygen and shade store the light's distance beside every ray they make
+    const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, stack_overflow != nullptr);
+    const uint32_t refill_at = (plan.mode == 0 || (plan.mode == 1 && plan.n_lds_nodes < n_nodes / 8u)) ? 32u : 16u;
+    const BouncesKernel kernel = bounces_kernel(plan, use_lt);
+    hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block)), dim3(plan.block), plan.bytes, s, scene, loop, n_nodes,
+                       refill_at, stack_entries, plan.n_lds_nodes, plan.stride, params, plan.lds_stack_entries, stack_overflow);
 }
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,

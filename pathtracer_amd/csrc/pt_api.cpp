@@ -160,6 +160,7 @@ struct pt_renderer {
     uint32_t region_size = 1024;              // slots per region, chosen from the batch size and the resident waves
     uint32_t region_size_env = 0;             // set through the environment (experiments)
     uint32_t extend_waves = 0;                // waves of the traversal kernel resident at once
+    uint32_t bounces_waves = 0;               // the same for the kernel that runs all bounces of a small batch
     uint64_t scene_hash = 0;                  // FNV-1a over the scene arrays (checkpoint compatibility)
     uint8_t *d_rgba8 = nullptr;               // emulated 8-bit accumulation texture (cfg.emulate_rgba8)
     uint32_t bvh_builder = 0;                 // the builder that made the tree (0 host, 1 device)
@@ -318,6 +319,9 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
                                                               r->d_stack_overflow[0] != nullptr)
                                    : r->n_cus * 32u;
         r->extend_waves = waves;
+        r->bounces_waves = r->cfg.use_bvh ? pt::bounces_resident_waves(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds,
+                                                                       r->d_stack_overflow[0] != nullptr)
+                                          : waves;
         size_t m = std::max<size_t>(1, (r->capacity + size_t(waves) * 1024) / (size_t(waves) * 2048));
         size_t size = (r->capacity + waves * m - 1) / (waves * m);
         size = std::max<size_t>(256, (size + 63) & ~size_t(63));
@@ -402,13 +406,35 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
 // Slots per region for a launch over n_items queue slots.  A full batch uses the size the buffers were laid out
 // for; a smaller one (the reference's one sample per draw) gets smaller regions, so that it still spreads over
 // all resident waves: the same rule as in alloc_paths, within what the count rows and the hit list can hold.
+// A small batch (the reference's one sample per draw) spends its time starting and draining 2 * depth - 1
+// kernels over thinning queues: all its bounces go in one launch instead (k_bounces), unless per-kernel
+// timing, the counters or the exact-samples pass are asked for.  Same results either way.
+constexpr size_t kFusedMaxPaths = size_t(1) << 23;  // measured on Box: one launch wins up to about 8 M paths (+15 % at 2 M, +2 % at 8 M), loses 2 % at 16 M
+bool bounces_in_one_launch(const pt_renderer *r, size_t n_paths)
+{
+    static const size_t fused_max_paths = [] {
+        const char *e = pt::tuning_env("PT_FUSED_MAX");  // tuning experiments only
+        return e ? static_cast<size_t>(std::atoll(e)) : kFusedMaxPaths;
+    }();
+    const bool exact_samples = r->cfg.emulate_rgba8 || (r->cfg.profile & 4u);
+    return r->cfg.use_bvh && !exact_samples && !(r->cfg.profile & 3u) && n_paths <= fused_max_paths;
+}
+
 uint32_t region_size_for(const pt_renderer *r, size_t n_items)
 {
     if (n_items >= r->capacity || r->region_size_env) return r->region_size;
-    const size_t waves = std::max<uint32_t>(1, r->extend_waves);
+    // as many equal regions as the kernel that will walk them keeps waves resident
+    const bool fused = bounces_in_one_launch(r, n_items);
+    const size_t waves = std::max<uint32_t>(1, fused ? r->bounces_waves : r->extend_waves);
     size_t m = std::max<size_t>(1, (n_items + waves * 1024) / (waves * 2048));
     size_t size = (n_items + waves * m - 1) / (waves * m);
-    size = std::max<size_t>(256, (size + 63) & ~size_t(63));
+    static const size_t min_region_env = [] {
+        const char *e = pt::tuning_env("PT_MIN_REGION");  // tuning experiments only
+        return e ? static_cast<size_t>(std::atoi(e)) : size_t(0);
+    }();
+    // (in one launch a wave walks its regions through every bounce: shorter regions, more waves at work)
+    const size_t min_region = min_region_env ? min_region_env : (fused ? size_t(128) : size_t(256));
+    size = std::max<size_t>(min_region, (size + 63) & ~size_t(63));
     // no more regions than a row of counts has entries
     const size_t at_least = (n_items + r->region_pitch - 1) / std::max<uint32_t>(1, r->region_pitch);
     size = std::max(size, (at_least + 63) & ~size_t(63));
@@ -515,6 +541,12 @@ void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
     // them): rays that escape are checked for planes they are exactly parallel to (a "hit" at t = inf in the
     // reference, a NaN sample), and the BSDF is evaluated at the last surface too.
     const bool exact_samples = r->cfg.emulate_rgba8 || (r->cfg.profile & 4u);
+    if (bounces_in_one_launch(r, n_paths)) {
+        const pt::Regions rg = regions_for(r, n_paths, 0, -1, d_counts);
+        pt::BounceLoop loop{{q[0], q[1]}, d_hits, d_samples, d_counts, r->region_pitch, rg.n_regions, rg.stride, rg.size, depth};
+        pt::launch_bounces(st, g, r->view, r->stack_entries, loop, bp, r->n_nodes, r->scene_in_lds, r->d_stack_overflow[lane]);
+        return;
+    }
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = q[b & 1], &out = q[(b + 1) & 1];
         // The last surface hit needs no new direction -- except that the reference still evaluates the BSDF

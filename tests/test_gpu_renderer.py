@@ -57,6 +57,39 @@ def test_two_streams_render_the_image_of_one(pt):
     assert np.array_equal(a, b) and np.all(a[..., 3] == 3)
 
 
+@pytest.mark.parametrize("name,lattice", [("Box", 0), ("Veggie", 0), ("Veggie", 3)])
+def test_all_bounces_in_one_launch_render_what_separate_launches_render(pt, name, lattice):
+    """A small batch runs all its bounces in one launch (a wave carries its regions of the queues through
+    traversal and shading of every bounce); per-kernel timing (profile bit 0) asks for one launch per
+    kernel instead.  Same image, same counts -- for a scene that lives in LDS in small blocks (Box), in one
+    large block (Veggie) and one whose tree is read from memory (38 890 triangles) -- and the same again
+    as a batch too large for the one launch."""
+    scene = pt.Scene.from_arrays(**scene_arrays(name))
+    if lattice:
+        scene = scene.instance_lattice(10, lattice)
+    out = []
+    for profile, width, calls in [(0, 256, [3, 3, 2]), (1, 256, [3, 3, 2]), (0, 256, [8])]:
+        r = pt.Renderer(scene, pt.Camera(resolution=(width, 192)), max_depth=7, profile=profile)
+        for c in calls:
+            r.draw(c)
+        out.append((r.read_sum(), r.stats()))
+        r.close()
+    for s, st in out[1:]:
+        assert np.array_equal(s, out[0][0])
+        assert st["segments"] == out[0][1]["segments"] and st["hits_shaded"] == out[0][1]["hits_shaded"]
+    assert np.isfinite(out[0][0]).all() and np.all(out[0][0][..., 3] == 8)
+    # 1080p: 4 samples per pixel (8.3 M paths) go in one launch, 32 do not
+    if not lattice:
+        big = []
+        for calls in ([4] * 8, [32]):
+            r = pt.Renderer(scene, pt.Camera(resolution=(1920, 1080)), max_depth=5)
+            for c in calls:
+                r.draw(c)
+            big.append(r.read_sum())
+            r.close()
+        assert np.array_equal(big[0], big[1])
+
+
 def test_deterministic_across_runs(pt):
     a = []
     for _ in range(2):
