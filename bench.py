@@ -147,14 +147,17 @@ def timed_run(pt, dist, args, scene_name, rank, world, device, reducer):
     return dt, r
 
 
-def kernel_profile(pt, args, scene_name, device, rank, world, batch_streams=2, counters=True):
+def kernel_profile(pt, args, scene_name, device, rank, world, batch_streams=2, counters=True, separate_launches=False):
     """Same workload with every launch bracketed by HIP events on the stream it is
     launched on (pt_config.profile).  batch_streams = 2: as in the timed run, the
     kernels of two batches overlap and a launch's duration includes what it shares
-    with the other batch; 1: every kernel alone on the GPU."""
+    with the other batch; 1: every kernel alone on the GPU.  separate_launches: one
+    launch per kernel and bounce also where the renderer would run all bounces of a
+    batch in one launch (profile bit 4), for the per-kernel breakdown."""
     cam = pt.Camera(resolution=(args.width, args.height))
     r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
-                    iterations_per_batch=args.batch_spp, profile=1, batch_streams=batch_streams)
+                    iterations_per_batch=args.batch_spp, profile=1 | (16 if separate_launches else 0),
+                    batch_streams=batch_streams)
     r.set_partition(rank, world)
     spp = max(1, spp_of_step(args, rank, world))
     r.draw(min(spp, args.batch_spp))  # warm
@@ -306,6 +309,11 @@ def main():
     # the same kernels one at a time (one stream): what a launch takes when it has the GPU to itself
     prof_alone = None if args.no_alone else kernel_profile(pt, args, args.scene, device, rank, world, batch_streams=1,
                                                             counters=False)
+    # where the timed run puts all bounces of a batch in one launch: the same work kernel by kernel, for the breakdown
+    prof_sep = None
+    if prof["launches_bounces"] and not args.no_alone:
+        prof_sep = kernel_profile(pt, args, args.scene, device, rank, world, batch_streams=1, counters=False,
+                                  separate_launches=True)
     out = None
     if rank == 0:
         seg = prof["segments"]
@@ -315,8 +323,13 @@ def main():
             extend_bytes = EXTEND_READ_PER_RAY * p["segments"] + EXTEND_WRITE_PER_HIT * shaded
             shade_bytes = SHADE_READ_PER_HIT * shaded + SHADE_WRITE_PER_SURVIVOR * shaded
             table = {
-                "extend": {"ms_total": p["ms_extend"], "launches": p["launches_extend"], "algorithmic_bytes": extend_bytes},
-                "shade": {"ms_total": p["ms_shade"], "launches": p["launches_shade"], "algorithmic_bytes": shade_bytes},
+                "extend": {"ms_total": p["ms_extend"], "launches": p["launches_extend"],
+                           "algorithmic_bytes": extend_bytes if p["launches_extend"] else 0},
+                "shade": {"ms_total": p["ms_shade"], "launches": p["launches_shade"],
+                          "algorithmic_bytes": shade_bytes if p["launches_shade"] else 0},
+                # all bounces of a batch in one launch (k_bounces): the traversal and shading of every bounce
+                "bounces": {"ms_total": p["ms_bounces"], "launches": p["launches_bounces"],
+                            "algorithmic_bytes": (extend_bytes + shade_bytes) if p["launches_bounces"] else 0},
                 "raygen": {"ms_total": p["ms_raygen"], "launches": p["launches_raygen"],
                            "algorithmic_bytes": RAYGEN_BYTES_PER_PATH * p["paths"]},
                 "accumulate": {"ms_total": p["ms_accumulate"], "launches": p["launches_accumulate"],
@@ -329,7 +342,7 @@ def main():
 
         kernels = kernel_table(prof)
         alone = kernel_table(prof_alone) if prof_alone else None
-        dom = max(("extend", "shade"), key=lambda n: kernels[n]["ms_total"])
+        dom = max(("extend", "shade", "bounces"), key=lambda n: kernels[n]["ms_total"])
         hbm_achieved = kernels[dom]["achieved_GBs"]
         # counted work for the flop view: box tests ~ 2 x 17 flops per node, triangle test ~ 85 flops
         flops = prof["nodes_visited"] * 44.0 + prof["tris_tested"] * 85.0 + seg * 60.0
@@ -343,7 +356,8 @@ def main():
             for name, m in allk.items():
                 # the render-loop instantiation: <BLOCK, COUNT, EXACT, SCENE_LDS, RENDER, USE_LT> = no counters, no exact pass, render
                 short = "extend" if re.fullmatch(r"k_extend_bvh<\d+, false, false, \d, true, (true|false)>", name) else \
-                    ("shade" if name == "k_shade" else None)
+                    ("shade" if name == "k_shade" else
+                     ("bounces" if re.fullmatch(r"k_bounces<\d+, \d, (true|false)>", name) else None))
                 if short:
                     pmc[short] = m
             if dom in pmc and "hbm_read_bytes_per_launch" in pmc[dom]:
@@ -376,10 +390,15 @@ def main():
                     # with the other batch's kernels.  One batch at a time (pt_config.batch_streams = 1):
                     "alone": {"avg_launch_ms": alone[dom]["avg_launch_ms"], "hbm_achieved_GBs": alone[dom]["achieved_GBs"],
                               "hbm_frac": alone[dom]["achieved_GBs"] / HBM_PEAK_GBS, "kernels": alone} if alone else None,
-                    "flop_view": {"extend_counted_gflop": flops / 1e9,
-                                  "extend_tflops": flops / max(prof["ms_extend"], 1e-9) / 1e9,
-                                  "peak_tflops": VALU_PEAK_TFLOPS,
-                                  "frac": flops / max(prof["ms_extend"], 1e-9) / 1e9 / VALU_PEAK_TFLOPS},
+                    # the timed run puts all bounces of a batch in one launch; the same work as one launch per kernel
+                    # and bounce, one batch at a time:
+                    "as_separate_launches": kernel_table(prof_sep) if prof_sep else None,
+                    # counted traversal work (box and triangle tests) over the time of the kernel(s) that did it
+                    "flop_view": (lambda ms: {"extend_counted_gflop": flops / 1e9,
+                                              "extend_tflops": flops / max(ms, 1e-9) / 1e9,
+                                              "peak_tflops": VALU_PEAK_TFLOPS,
+                                              "frac": flops / max(ms, 1e-9) / 1e9 / VALU_PEAK_TFLOPS})(
+                        prof["ms_extend"] + prof["ms_bounces"]),
                     "kernels": kernels}
         # The whole pipeline against HBM: algorithmic bytes of all kernels of a step over the step's wall time.
         bytes_per_path = sum(k["algorithmic_bytes"] for k in kernels.values()) / max(1, prof["paths"])

@@ -77,7 +77,10 @@ typedef struct {
                                       bit 3 (for tests): a tree too large for on-chip memory
                                       is traversed with only 4 entries of each ray's stack
                                       on chip, so that the overflow buffer, which otherwise
-                                      holds entries 17 and up, is used by most rays       */
+                                      holds entries 17 and up, is used by most rays;
+                                      bit 4: one launch per kernel and bounce even where all
+                                      bounces of a batch would go in one launch (per-kernel
+                                      timings with bit 0; the image is the same)           */
     uint32_t emulate_rgba8;        /* 1: beside the float sum, keep the reference's own
                                       accumulator: an 8-bit RGBA texel per pixel updated as
                                       (accum*it + sample)/(it+1) and re-quantised every
@@ -125,6 +128,11 @@ typedef struct {
     uint64_t hits_shaded, shade_batches;
     uint32_t bvh_builder;     /* the builder that made the tree: 0 host, 1 device */
     uint32_t reserved;
+    /* Batches whose bounces all ran in one launch (small batches, and every batch of a scene that lives on
+     * chip in small blocks): duration and count of those launches (profile bit 0); ms_extend / ms_shade then
+     * cover only the batches that were launched kernel by kernel. */
+    double ms_bounces;
+    uint64_t launches_bounces;
 } pt_stats;
 
 const char *pt_last_error(void);

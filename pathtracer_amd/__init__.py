@@ -113,6 +113,8 @@ class Stats(C.Structure):
         ("shade_batches", C.c_uint64),
         ("bvh_builder", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("ms_bounces", C.c_double),
+        ("launches_bounces", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:

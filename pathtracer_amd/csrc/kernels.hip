@@ -1300,8 +1300,12 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
 // CU's cache, through which it also reads).  Against 2 * depth - 1 launches this removes the start-up and drain
 // of kernels over thinning queues, which is what a small batch -- the reference's one sample per draw -- spends
 // its time on.  Render loop only: no counters, no exact pass.
+// Small blocks are compiled for five waves per SIMD (102 registers; the shading code alone takes 107 at four):
+// when the whole scene is in LDS in small blocks, five of them per CU retire and are replaced one by one, and
+// the kernel then beats the separate launches at every batch size (Box +4 %).  One block of 1024 threads per
+// CU cannot overlap its waves' tails with anything (Veggie -8 % on large batches).
 template <int BLOCK, int SCENE_LDS, bool USE_LT>
-__global__ void __launch_bounds__(BLOCK, 4) k_bounces(SceneView sc, BounceLoop L, uint32_t n_nodes, uint32_t refill_at,
+__global__ void __launch_bounds__(BLOCK, BLOCK == 256 ? 5 : 4) k_bounces(SceneView sc, BounceLoop L, uint32_t n_nodes, uint32_t refill_at,
                                                       uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
                                                       const BatchParams *__restrict__ bp, uint32_t lds_stack_entries,
                                                       int *stack_overflow)
@@ -1793,6 +1797,12 @@ uint32_t bounces_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t
     int per_cu = blocks_per_cu(reinterpret_cast<const void *>(bounces_kernel(plan, scene.n_lights == 1u)), plan.block, plan.bytes);
     if (per_cu < 1) per_cu = 1;
     return n_cus * static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(plan.block / 64);
+}
+
+bool bounces_suit_any_batch(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds, bool overflow_buffer)
+{
+    const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, overflow_buffer);
+    return plan.block == 256 && plan.mode >= 2;
 }
 
 void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, const BounceLoop &loop,

@@ -160,7 +160,8 @@ struct pt_renderer {
     uint32_t region_size = 1024;              // slots per region, chosen from the batch size and the resident waves
     uint32_t region_size_env = 0;             // set through the environment (experiments)
     uint32_t extend_waves = 0;                // waves of the traversal kernel resident at once
-    uint32_t bounces_waves = 0;               // the same for the kernel that runs all bounces of a small batch
+    uint32_t bounces_waves = 0;               // the same for the kernel that runs all bounces of a batch in one launch
+    bool bounces_any_size = false;            // that kernel serves this scene best at every batch size (kernels.h)
     uint64_t scene_hash = 0;                  // FNV-1a over the scene arrays (checkpoint compatibility)
     uint8_t *d_rgba8 = nullptr;               // emulated 8-bit accumulation texture (cfg.emulate_rgba8)
     uint32_t bvh_builder = 0;                 // the builder that made the tree (0 host, 1 device)
@@ -195,11 +196,11 @@ struct pt_renderer {
     uint64_t paths = 0;
 
     // profile
-    double ms[4] = {0, 0, 0, 0};
-    uint64_t launches[4] = {0, 0, 0, 0};
+    double ms[5] = {0, 0, 0, 0, 0};
+    uint64_t launches[5] = {0, 0, 0, 0, 0};
     struct TimedLaunch {
         hipEvent_t begin, end;
-        int kernel;  // 0 raygen, 1 extend, 2 shade, 3 accumulate
+        int kernel;  // 0 raygen, 1 extend, 2 shade, 3 accumulate, 4 all bounces in one launch
     };
     std::vector<TimedLaunch> timed;
 
@@ -322,6 +323,8 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         r->bounces_waves = r->cfg.use_bvh ? pt::bounces_resident_waves(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds,
                                                                        r->d_stack_overflow[0] != nullptr)
                                           : waves;
+        r->bounces_any_size = r->cfg.use_bvh && pt::bounces_suit_any_batch(r->view, r->stack_entries, r->n_nodes, r->scene_in_lds,
+                                                                         r->d_stack_overflow[0] != nullptr);
         size_t m = std::max<size_t>(1, (r->capacity + size_t(waves) * 1024) / (size_t(waves) * 2048));
         size_t size = (r->capacity + waves * m - 1) / (waves * m);
         size = std::max<size_t>(256, (size + 63) & ~size_t(63));
@@ -407,8 +410,9 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
 // for; a smaller one (the reference's one sample per draw) gets smaller regions, so that it still spreads over
 // all resident waves: the same rule as in alloc_paths, within what the count rows and the hit list can hold.
 // A small batch (the reference's one sample per draw) spends its time starting and draining 2 * depth - 1
-// kernels over thinning queues: all its bounces go in one launch instead (k_bounces), unless per-kernel
-// timing, the counters or the exact-samples pass are asked for.  Same results either way.
+// kernels over thinning queues: all its bounces go in one launch instead (k_bounces) -- and so do the large
+// batches of a scene that kernel suits at any size -- unless one launch per kernel (profile bit 4), the
+// counters or the exact-samples pass are asked for.  Same results either way.
 constexpr size_t kFusedMaxPaths = size_t(1) << 23;  // measured on Box: one launch wins up to about 8 M paths (+15 % at 2 M, +2 % at 8 M), loses 2 % at 16 M
 bool bounces_in_one_launch(const pt_renderer *r, size_t n_paths)
 {
@@ -417,7 +421,9 @@ bool bounces_in_one_launch(const pt_renderer *r, size_t n_paths)
         return e ? static_cast<size_t>(std::atoll(e)) : kFusedMaxPaths;
     }();
     const bool exact_samples = r->cfg.emulate_rgba8 || (r->cfg.profile & 4u);
-    return r->cfg.use_bvh && !exact_samples && !(r->cfg.profile & 3u) && n_paths <= fused_max_paths;
+    static const bool never_any_size = pt::tuning_env("PT_FUSED_SMALL_ONLY") != nullptr;  // tuning experiments only
+    return r->cfg.use_bvh && !exact_samples && !(r->cfg.profile & (2u | 16u)) &&
+           (n_paths <= fused_max_paths || (r->bounces_any_size && !never_any_size));
 }
 
 uint32_t region_size_for(const pt_renderer *r, size_t n_items)
@@ -477,7 +483,7 @@ int reset_accumulation(pt_renderer *r)
     mark_main_stream_work(r);
     r->local_iterations = 0;
     r->paths = 0;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 5; ++k) {
         r->ms[k] = 0;
         r->launches[k] = 0;
     }
@@ -544,6 +550,7 @@ void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
     if (bounces_in_one_launch(r, n_paths)) {
         const pt::Regions rg = regions_for(r, n_paths, 0, -1, d_counts);
         pt::BounceLoop loop{{q[0], q[1]}, d_hits, d_samples, d_counts, r->region_pitch, rg.n_regions, rg.stride, rg.size, depth};
+        Timed t(r, 4, st);
         pt::launch_bounces(st, g, r->view, r->stack_entries, loop, bp, r->n_nodes, r->scene_in_lds, r->d_stack_overflow[lane]);
         return;
     }
@@ -1709,6 +1716,8 @@ int pt_get_stats(pt_renderer *r, pt_stats *s)
     s->launches_extend = r->launches[1];
     s->launches_shade = r->launches[2];
     s->launches_accumulate = r->launches[3];
+    s->ms_bounces = r->ms[4];
+    s->launches_bounces = r->launches[4];
     s->sah_cost = r->sah_cost;
     for (int k = 0; k < 8; ++k) s->extend_diag[k] = c[4 + k];
     s->hits_shaded = c[12];

@@ -57,7 +57,7 @@ def run(name, scene_name, lattice, w, h, depth, spp, batches):
     out["segments_per_path"] = st["segments"] / st["paths"]
     out["mrays_per_s"] = st["segments"] / dt / 1e6
     out["stack_entries"] = st["stack_entries"]
-    r = pt.Renderer(scene, cam, max_depth=depth, iterations_per_batch=spp, profile=1)
+    r = pt.Renderer(scene, cam, max_depth=depth, iterations_per_batch=spp, profile=1 | 16)  # per-kernel times: one launch per kernel
     r.draw(spp)
     r.synchronize()
     r.reset()
