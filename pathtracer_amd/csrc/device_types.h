@@ -53,6 +53,7 @@ struct DeviceCamera {
     uint32_t tiles_x;     // tiles per image row (mode 2)
     // Division by three run-time constants without a divide: x / d = umulhi(x, magic) >> shift for x < 2^31.
     FastDiv div_pixels, div_tiles_x, div_width;
+    FastDiv div_map_units;  // valid when (map_units - 1) * map_stride < 2^31; magic = 0xFFFFFFFF says it is not
 };
 
 }  // namespace pt

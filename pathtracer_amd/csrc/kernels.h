@@ -125,8 +125,8 @@ uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t 
 size_t extend_stack_overflow_bytes(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes,
                                    bool scene_in_lds);
 
-// Every bounce of a batch in one launch (k_bounces): the launches launch_extend / launch_shade would make for
-// bounces 0 .. depth-1 of the render loop (no counters, no exact-samples pass), with the same results.
+// A whole batch in one launch (k_bounces): what launch_raygen and then launch_extend / launch_shade for bounces
+// 0 .. depth-1 of the render loop would do (no counters, no exact-samples pass), with the same results.
 struct BounceLoop {
     PathQueue q[2];    // bounce b reads q[b & 1] and writes q[(b + 1) & 1]
     float4 *hit_list;
@@ -141,7 +141,8 @@ uint32_t bounces_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t
 // measured: Box and the Anisotropic scenes +3-6 %, scenes in one large block per CU -8 %, trees in memory -5 %).
 bool bounces_suit_any_batch(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds, bool overflow_buffer);
 void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, const BounceLoop &loop,
-                    const BatchParams *params, uint32_t n_nodes, bool scene_in_lds, int *stack_overflow);
+                    const BatchParams *params, uint32_t n_nodes, bool scene_in_lds, int *stack_overflow, uint32_t it_stride,
+                    uint32_t n_iterations);
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
                   const float4 *hit_list, PathQueue out, float4 *samples /* receives the sample of a path whose ray went non-finite */,

@@ -130,7 +130,11 @@ __device__ __forceinline__ uint32_t pixel_of_slot(const DeviceCamera &cam, uint3
     // unit u of the queue = unit (u * stride) mod n of the image, stride near n / golden ratio and coprime to n:
     // any run of consecutive units (a region) is spread evenly over the whole image.  (A cheaper permutation by
     // bit reversal was measured: traversal 10 % slower -- the waves' shares of the work are less equal.)
-    const uint32_t unit = static_cast<uint32_t>((static_cast<unsigned long long>(u) * cam.map_stride) % cam.map_units);
+    uint32_t unit;
+    if (cam.div_map_units.magic != 0xFFFFFFFFu)  // the usual case: the product fits in 31 bits
+        (void)div_by(u * cam.map_stride, cam.map_units, cam.div_map_units, unit);
+    else
+        unit = static_cast<uint32_t>((static_cast<unsigned long long>(u) * cam.map_stride) % cam.map_units);
     const uint32_t in_unit = j & 63u;
     if (cam.map_mode == 1u) return (unit << 6) + in_unit;
     uint32_t tx;
@@ -157,6 +161,38 @@ __global__ void __launch_bounds__(64) k_set_batch(BatchParams *params, DeviceCam
     }
 }
 
+// The camera's frame as the ray generation uses it (frag:306-320).
+struct PrimaryFrame {
+    f3 eye, ref, H, V;
+};
+__device__ __forceinline__ PrimaryFrame primary_frame(const DeviceCamera &cam)
+{
+    const f3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
+    const f3 fwd = mk(cam.forward[0], cam.forward[1], cam.forward[2]);
+    const f3 up = mk(cam.up[0], cam.up[1], cam.up[2]);
+    const f3 right = mk(cam.right[0], cam.right[1], cam.right[2]);
+    return PrimaryFrame{eye, eye + fwd, (right * cam.tan_half_fov) * cam.aspect, up * cam.tan_half_fov};
+}
+// The primary ray of pixel (x, y) in iteration `iteration`, written to slot i of the queue.
+__device__ __forceinline__ void write_primary_ray(const SceneView &sc, const DeviceCamera &cam, const PrimaryFrame &f, uint32_t x,
+                                                  uint32_t y, uint32_t iteration, const PathQueue &out, uint32_t i)
+{
+    const float fx = static_cast<float>(x) + 0.5f, fy = static_cast<float>(y) + 0.5f;
+    uint32_t sx = (iteration + 1u) * x;
+    uint32_t sy = (iteration + 2u) * y;
+    const float jx = rng_next(sx, sy);
+    const float jy = rng_next(sx, sy);
+    float scx = (fx + jx) / cam.width_f;
+    float scy = (fy + jy) / cam.height_f;
+    scx = scx * 2.f - 1.f;
+    scy = scy * 2.f - 1.f;
+    const f3 p = (f.ref + f.H * scx) + f.V * scy;
+    const f3 d = normalizem(p - f.eye);
+    out.p0[i] = make_float4(f.eye.x, f.eye.y, f.eye.z, d.x);
+    out.p1[i] = make_float4(d.y, d.z, __uint_as_float(sx), __uint_as_float(sy));
+    if (sc.n_lights == 1u) out.lt[i] = light_distance(sc.lights[0], f.eye, d);
+}
+
 __global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, const BatchParams *__restrict__ bp, uint32_t it_stride,
                                                     uint32_t n_iterations, PathQueue out, uint32_t *counts_out,
                                                     uint32_t region_slots)
@@ -165,37 +201,15 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, const BatchPara
     const uint32_t it_first = bp->it_first;
     const uint32_t n_pixels = cam.width * cam.height;
     const uint32_t total = n_pixels * n_iterations;
-    const f3 eye = mk(cam.eye[0], cam.eye[1], cam.eye[2]);
-    const f3 fwd = mk(cam.forward[0], cam.forward[1], cam.forward[2]);
-    const f3 up = mk(cam.up[0], cam.up[1], cam.up[2]);
-    const f3 right = mk(cam.right[0], cam.right[1], cam.right[2]);
-    const f3 ref = eye + fwd;
-    const f3 V = up * cam.tan_half_fov;
-    const f3 H = (right * cam.tan_half_fov) * cam.aspect;
+    const PrimaryFrame frame = primary_frame(cam);
     // A thread takes slot j of every iteration of the batch: the slot -> pixel arithmetic is done once for all
     // of them, and the stores of one iteration are still consecutive over the threads.
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < n_pixels; j += gridDim.x * kBlock) {
         const uint32_t pixel = pixel_of_slot(cam, j);
         uint32_t x;
         const uint32_t y = div_by(pixel, cam.width, cam.div_width, x);
-        const float fx = static_cast<float>(x) + 0.5f, fy = static_cast<float>(y) + 0.5f;
-        for (uint32_t k = 0; k < n_iterations; ++k) {
-            const uint32_t i = k * n_pixels + j;
-            const uint32_t iteration = it_first + k * it_stride;
-            uint32_t sx = (iteration + 1u) * x;
-            uint32_t sy = (iteration + 2u) * y;
-            const float jx = rng_next(sx, sy);
-            const float jy = rng_next(sx, sy);
-            float scx = (fx + jx) / cam.width_f;
-            float scy = (fy + jy) / cam.height_f;
-            scx = scx * 2.f - 1.f;
-            scy = scy * 2.f - 1.f;
-            const f3 p = (ref + H * scx) + V * scy;
-            const f3 d = normalizem(p - eye);
-            out.p0[i] = make_float4(eye.x, eye.y, eye.z, d.x);
-            out.p1[i] = make_float4(d.y, d.z, __uint_as_float(sx), __uint_as_float(sy));
-            if (sc.n_lights == 1u) out.lt[i] = light_distance(sc.lights[0], eye, d);
-        }
+        for (uint32_t k = 0; k < n_iterations; ++k)
+            write_primary_ray(sc, cam, frame, x, y, it_first + k * it_stride, out, k * n_pixels + j);
     }
     // rays per region of the new queue: full regions and a ragged last one
     const uint32_t n_regions = (total + region_slots - 1u) / region_slots;
@@ -1292,7 +1306,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
 
 // ------------------------------------------------- all bounces in one launch
 
-// raygen's output through every bounce of the batch in ONE launch.  A region's data never leaves its wave: the
+// A batch from its primary rays through every bounce in ONE launch.  A region's data never leaves its wave: the
 // traversal reads region r of the ray queue and writes region r of the hit list, the shading reads those and
 // writes region r of the other queue, and a wave visits the same regions in both (turns k, k + n_waves, ... of
 // the same grid).  So a wave carries its regions through all bounces with no synchronisation between waves;
@@ -1304,13 +1318,46 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
 // when the whole scene is in LDS in small blocks, five of them per CU retire and are replaced one by one, and
 // the kernel then beats the separate launches at every batch size (Box +4 %).  One block of 1024 threads per
 // CU cannot overlap its waves' tails with anything (Veggie -8 % on large batches).
+// The primary rays are region-local as well: slot i of the queue is sample i / (W * H) of the pixel that slot
+// i mod (W * H) maps to, so the wave that will trace a region also makes its rays (what k_raygen does for the
+// whole queue at once), and reads them back from the cache rather than from memory.
+template <int BLOCK>
+__device__ __forceinline__ void raygen_regions(const SceneView &sc, const BatchParams *bp, uint32_t it_stride, uint32_t n_iterations,
+                                               const PathQueue &out, const Regions &rg)
+{
+    const DeviceCamera cam = bp->cam;
+    const uint32_t it_first = bp->it_first;
+    const uint32_t n_pixels = cam.width * cam.height;
+    const uint32_t total = n_pixels * n_iterations;
+    const PrimaryFrame frame = primary_frame(cam);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64);
+    for (uint32_t k = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); k < rg.n_regions; k += n_waves) {
+        const uint32_t r = region_of(rg, k);
+        const uint32_t base = r * rg.size, n = min(rg.size, total - base);
+        for (uint32_t i = base + lane; i < base + n; i += 64u) {
+            uint32_t j;
+            const uint32_t it = div_by(i, n_pixels, cam.div_pixels, j);
+            uint32_t x;
+            const uint32_t y = div_by(pixel_of_slot(cam, j), cam.width, cam.div_width, x);
+            write_primary_ray(sc, cam, frame, x, y, it_first + it * it_stride, out, i);
+        }
+        if (lane == 0) rg.counts_out[r] = n;
+    }
+}
+
 template <int BLOCK, int SCENE_LDS, bool USE_LT>
 __global__ void __launch_bounds__(BLOCK, BLOCK == 256 ? 5 : 4) k_bounces(SceneView sc, BounceLoop L, uint32_t n_nodes, uint32_t refill_at,
                                                       uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
                                                       const BatchParams *__restrict__ bp, uint32_t lds_stack_entries,
-                                                      int *stack_overflow)
+                                                      int *stack_overflow, uint32_t it_stride, uint32_t n_iterations)
 {
     const TraversalCounters no_counters{nullptr, nullptr, nullptr};
+    {
+        const Regions rg{nullptr, L.counts, L.n_regions, L.stride, L.size};
+        raygen_regions<BLOCK>(sc, bp, it_stride, n_iterations, L.q[0], rg);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
     for (uint32_t b = 0; b < L.depth; ++b) {
         const uint32_t last = b + 1u == L.depth ? 1u : 0u;
         uint32_t *rays = L.counts + static_cast<size_t>(b) * L.pitch, *hits = L.counts + static_cast<size_t>(L.depth + 1u + b) * L.pitch;
@@ -1770,7 +1817,8 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
 }
 
 namespace {
-using BouncesKernel = void (*)(SceneView, BounceLoop, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const BatchParams *, uint32_t, int *);
+using BouncesKernel = void (*)(SceneView, BounceLoop, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const BatchParams *, uint32_t, int *,
+                               uint32_t, uint32_t);
 template <int BLOCK, int L>
 BouncesKernel bounces_kernel_for(bool use_lt)
 {
@@ -1806,14 +1854,16 @@ bool bounces_suit_any_batch(const SceneView &scene, uint32_t stack_entries, uint
 }
 
 void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, const BounceLoop &loop,
-                    const BatchParams *params, uint32_t n_nodes, bool scene_in_lds, int *stack_overflow)
+                    const BatchParams *params, uint32_t n_nodes, bool scene_in_lds, int *stack_overflow, uint32_t it_stride,
+                    uint32_t n_iterations)
 {
     const bool use_lt = scene.n_lights == 1u;  // raygen and shade store the light's distance beside every ray they make
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, stack_overflow != nullptr);
     const uint32_t refill_at = (plan.mode == 0 || (plan.mode == 1 && plan.n_lds_nodes < n_nodes / 8u)) ? 32u : 16u;
     const BouncesKernel kernel = bounces_kernel(plan, use_lt);
-    hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block)), dim3(plan.block), plan.bytes, s, scene, loop, n_nodes,
-                       refill_at, stack_entries, plan.n_lds_nodes, plan.stride, params, plan.lds_stack_entries, stack_overflow);
+    hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block, "PT_BOUNCES_PER_CU")), dim3(plan.block), plan.bytes, s, scene, loop, n_nodes,
+                       refill_at, stack_entries, plan.n_lds_nodes, plan.stride, params, plan.lds_stack_entries, stack_overflow, it_stride,
+                       n_iterations);
 }
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,

@@ -397,6 +397,9 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         r->cam.div_pixels = pt::make_fast_div(n_px);
         r->cam.div_tiles_x = pt::make_fast_div(std::max(1u, r->cam.tiles_x));
         r->cam.div_width = pt::make_fast_div(width);
+        r->cam.div_map_units = pt::make_fast_div(std::max(1u, r->cam.map_units));
+        if (static_cast<unsigned long long>(r->cam.map_units) * r->cam.map_stride >= (1ull << 31))
+            r->cam.div_map_units.magic = 0xFFFFFFFFu;  // the product does not fit: pixel_of_slot divides in 64 bits
     }
     return PT_OK;
 }
@@ -539,10 +542,6 @@ void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
     float4 *d_hits = lane ? r->d_hits2 : r->d_hits, *d_samples = lane ? r->d_samples2 : r->d_samples;
     uint32_t *d_counts = lane ? r->d_counts2 : r->d_counts;
     const pt::BatchParams *bp = r->d_params + lane;
-    {
-        Timed t(r, 0, st);
-        pt::launch_raygen(st, g, r->view, bp, r->world, kb, q[0], d_counts, region_size_for(r, n_paths));
-    }
     // The reference's non-finite samples one for one (the 8-bit emulation needs them, profile bit 2 asks for
     // them): rays that escape are checked for planes they are exactly parallel to (a "hit" at t = inf in the
     // reference, a NaN sample), and the BSDF is evaluated at the last surface too.
@@ -551,8 +550,12 @@ void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
         const pt::Regions rg = regions_for(r, n_paths, 0, -1, d_counts);
         pt::BounceLoop loop{{q[0], q[1]}, d_hits, d_samples, d_counts, r->region_pitch, rg.n_regions, rg.stride, rg.size, depth};
         Timed t(r, 4, st);
-        pt::launch_bounces(st, g, r->view, r->stack_entries, loop, bp, r->n_nodes, r->scene_in_lds, r->d_stack_overflow[lane]);
+        pt::launch_bounces(st, g, r->view, r->stack_entries, loop, bp, r->n_nodes, r->scene_in_lds, r->d_stack_overflow[lane], r->world, kb);
         return;
+    }
+    {
+        Timed t(r, 0, st);
+        pt::launch_raygen(st, g, r->view, bp, r->world, kb, q[0], d_counts, region_size_for(r, n_paths));
     }
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = q[b & 1], &out = q[(b + 1) & 1];
