@@ -329,9 +329,10 @@ def main():
                           "algorithmic_bytes": shade_bytes if p["launches_shade"] else 0},
                 # all bounces of a batch in one launch (k_bounces): the traversal and shading of every bounce
                 "bounces": {"ms_total": p["ms_bounces"], "launches": p["launches_bounces"],
-                            "algorithmic_bytes": (extend_bytes + shade_bytes) if p["launches_bounces"] else 0},
+                            "algorithmic_bytes": (extend_bytes + shade_bytes + RAYGEN_BYTES_PER_PATH * p["paths"])
+                            if p["launches_bounces"] else 0},  # the kernel also makes the primary rays
                 "raygen": {"ms_total": p["ms_raygen"], "launches": p["launches_raygen"],
-                           "algorithmic_bytes": RAYGEN_BYTES_PER_PATH * p["paths"]},
+                           "algorithmic_bytes": RAYGEN_BYTES_PER_PATH * p["paths"] if p["launches_raygen"] else 0},
                 "accumulate": {"ms_total": p["ms_accumulate"], "launches": p["launches_accumulate"],
                                "algorithmic_bytes": SAMPLE_BYTES * p["paths"] + 32 * n_pixels * p["launches_accumulate"]},
             }
