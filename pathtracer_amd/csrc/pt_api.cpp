@@ -294,6 +294,23 @@ uint32_t batch_iterations_for(const pt_renderer *r, uint32_t width, uint32_t hei
 
 // Frees the path buffers and allocates them for width x height.  On failure the renderer holds no (or only
 // part of the) buffers: the caller either restores a size that worked or marks the renderer unusable.
+// Slots a region should have, about: with 64 M slots per batch this makes one region per resident wave (12 to 16
+// thousand slots; the two-ended hit list packs its counts into 16 bits each, so at most 32768).  The kernels'
+// per-region work -- opening a region, draining its last rays, the part-filled batches at both ends of its hit
+// list -- is then paid once per wave and bounce, and every wave still gets the same mix of the image because
+// consecutive slots are scattered over it.  Measured against regions of 2048 slots: Veggie +19 %, the
+// Transmission scenes +7-11 %, Box +3 %, the 10 M-triangle scene +3 %.
+size_t region_target_slots()
+{
+    static const size_t v = [] {
+        const char *e = pt::tuning_env("PT_REGION_TARGET");  // tuning experiments only
+        return e ? static_cast<size_t>(std::max(64, std::atoi(e))) : size_t(16384);
+    }();
+    return v;
+}
+
+bool bounces_in_one_launch(const pt_renderer *r, size_t n_paths);
+
 int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
 {
     const uint32_t k = batch_iterations_for(r, width, height);
@@ -311,21 +328,21 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         PT_HIP(hipMalloc(&r->q[b].lt, r->capacity * sizeof(float)));
     }
     {
-        // Region size.  The traversal kernel runs `waves` persistent waves; every wave should get the same
-        // whole number m of regions (a wave with one region more than the others sets the kernel's run time),
-        // regions of about 2048 slots amortise the per-region work best, and the two-ended hit list packs its
-        // counts into 16 bits each.  size = capacity / (waves * m), rounded up to a multiple of 64.
-        const uint32_t waves = r->cfg.use_bvh
-                                   ? pt::extend_resident_waves(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds,
-                                                              r->d_stack_overflow[0] != nullptr)
-                                   : r->n_cus * 32u;
-        r->extend_waves = waves;
+        // Region size.  The kernel that walks the regions runs `waves` persistent waves; every wave should get
+        // the same whole number m of regions (a wave with one region more than the others sets the kernel's run
+        // time) of about region_target_slots() slots.  size = capacity / (waves * m), rounded up to a multiple of 64.
+        r->extend_waves = r->cfg.use_bvh
+                              ? pt::extend_resident_waves(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds,
+                                                          r->d_stack_overflow[0] != nullptr)
+                              : r->n_cus * 32u;
         r->bounces_waves = r->cfg.use_bvh ? pt::bounces_resident_waves(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds,
                                                                        r->d_stack_overflow[0] != nullptr)
-                                          : waves;
+                                          : r->extend_waves;
         r->bounces_any_size = r->cfg.use_bvh && pt::bounces_suit_any_batch(r->view, r->stack_entries, r->n_nodes, r->scene_in_lds,
                                                                          r->d_stack_overflow[0] != nullptr);
-        size_t m = std::max<size_t>(1, (r->capacity + size_t(waves) * 1024) / (size_t(waves) * 2048));
+        const uint32_t waves = bounces_in_one_launch(r, r->capacity) ? r->bounces_waves : r->extend_waves;
+        const size_t target = region_target_slots();
+        size_t m = std::max<size_t>(1, (r->capacity + size_t(waves) * (target / 2)) / (size_t(waves) * target));
         size_t size = (r->capacity + waves * m - 1) / (waves * m);
         size = std::max<size_t>(256, (size + 63) & ~size_t(63));
         while (size > 32768) size = ((size / 2) + 63) & ~size_t(63);
@@ -435,7 +452,8 @@ uint32_t region_size_for(const pt_renderer *r, size_t n_items)
     // as many equal regions as the kernel that will walk them keeps waves resident
     const bool fused = bounces_in_one_launch(r, n_items);
     const size_t waves = std::max<uint32_t>(1, fused ? r->bounces_waves : r->extend_waves);
-    size_t m = std::max<size_t>(1, (n_items + waves * 1024) / (waves * 2048));
+    const size_t target = region_target_slots();
+    size_t m = std::max<size_t>(1, (n_items + waves * (target / 2)) / (waves * target));
     size_t size = (n_items + waves * m - 1) / (waves * m);
     static const size_t min_region_env = [] {
         const char *e = pt::tuning_env("PT_MIN_REGION");  // tuning experiments only
