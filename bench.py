@@ -3,9 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one 256-spp render (`--spp-per-step`; the sample count of the
-benchmark configurations) of the scene at 1920x1080, max depth 8, on every rank,
-issued as batches of 32 samples per pixel (weak scaling: rank g of G renders
+A step is 512 samples per pixel (`--spp-per-step`: two of the 256-spp renders of
+the benchmark configurations, so that a step stays above 100 ms -- 4.3 G paths at
+1080p) of the scene at 1920x1080, max depth 8, on every rank, issued as batches
+of 32 samples per pixel (weak scaling: rank g of G renders
 iterations g, g+G, ...).  With `--total-spp N` a step is instead one render of N
 samples per pixel IN TOTAL, split over the ranks (strong scaling: the 4K
 configurations with 1024 / 4096 spp).  The per-GPU radiance sums are combined
@@ -58,7 +59,7 @@ def parse_args():
     p.add_argument("--width", type=int, default=1920)
     p.add_argument("--height", type=int, default=1080)
     p.add_argument("--depth", type=int, default=8)
-    p.add_argument("--spp-per-step", type=int, default=256,
+    p.add_argument("--spp-per-step", type=int, default=512,
                    help="samples per pixel one step renders on every rank (weak scaling)")
     p.add_argument("--batch-spp", type=int, default=32, help="samples per pixel in flight together (pt_config.iterations_per_batch)")
     p.add_argument("--batch-streams", type=int, default=2, choices=(1, 2),
