@@ -350,6 +350,27 @@ def test_converged_image_against_reference(pt, name, depth):
     assert 3.0 < st["segments"] / st["paths"] < 5.0
 
 
+@pytest.mark.parametrize("name", CONFIG_SCENES)
+def test_short_render_agrees_with_the_oracle_pixel_by_pixel(pt, ob, name):
+    """The same paths on both sides (the RNG is integer-exact, the intersections bit-exact): after 8 samples
+    per pixel at depth 8 nearly every pixel of the sum agrees with the oracle's to float noise; the ones that
+    do not are paths that a last-bit difference in the BSDF arithmetic sent elsewhere (measured: 0.07 % of
+    Box's pixels, none in the other five scenes).  Channel means within 1e-4."""
+    w, h, spp, depth = 192, 108, 8, 8
+    r = _renderer(pt, name, w, h, max_depth=depth)
+    r.draw(spp)
+    s = r.read_sum()
+    r.close()
+    osum, _ = ob.render(ob.OracleScene(scene_arrays(name)), ob.make_camera(*default_camera_axes(), w, h), 0, spp, depth,
+                        min(16, os.cpu_count() or 1))
+    assert np.all(s[..., 3] == spp) and np.all(osum[..., 3] == spp)
+    close = np.isclose(s[..., :3], osum[..., :3], rtol=1e-3, atol=1e-4).all(axis=2).mean()
+    m, om = s[..., :3].mean(axis=(0, 1)), osum[..., :3].mean(axis=(0, 1))
+    print(f"{name}: {close:.4f} of the pixels agree; channel means {m} vs {om}")
+    assert close >= 0.998, f"only {close:.4f} of the pixels agree with the oracle"
+    assert np.all(np.abs(m - om) <= 1e-4 * om + 1e-7)
+
+
 def test_image_equivalence_bvh_vs_scan(pt):
     """Same closest hits => the two extend kernels give identical images."""
     out = []
