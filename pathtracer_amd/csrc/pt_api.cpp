@@ -422,13 +422,6 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
 }
 
 
-// Region bookkeeping for a launch over n_items queue slots: wave w visits the
-// regions (k * stride) mod n_regions, k = w, w + n_waves, ...; a stride near
-// the golden ratio of n_regions, coprime to it, scatters neighbouring image
-// areas over different waves.
-// Slots per region for a launch over n_items queue slots.  A full batch uses the size the buffers were laid out
-// for; a smaller one (the reference's one sample per draw) gets smaller regions, so that it still spreads over
-// all resident waves: the same rule as in alloc_paths, within what the count rows and the hit list can hold.
 // A small batch (the reference's one sample per draw) spends its time starting and draining 2 * depth - 1
 // kernels over thinning queues: all its bounces go in one launch instead (k_bounces) -- and so do the large
 // batches of a scene that kernel suits at any size -- unless one launch per kernel (profile bit 4), the
@@ -446,6 +439,9 @@ bool bounces_in_one_launch(const pt_renderer *r, size_t n_paths)
            (n_paths <= fused_max_paths || (r->bounces_any_size && !never_any_size));
 }
 
+// Slots per region for a launch over n_items queue slots.  A full batch uses the size the buffers were laid out
+// for; a smaller one (the reference's one sample per draw) gets smaller regions, so that it still spreads over
+// all resident waves: the same rule as in alloc_paths, within what the count rows and the hit list can hold.
 uint32_t region_size_for(const pt_renderer *r, size_t n_items)
 {
     if (n_items >= r->capacity || r->region_size_env) return r->region_size;
@@ -471,6 +467,10 @@ uint32_t region_size_for(const pt_renderer *r, size_t n_items)
     return static_cast<uint32_t>(size);
 }
 
+// Region bookkeeping for a launch over n_items queue slots: wave w visits the
+// regions (k * stride) mod n_regions, k = w, w + n_waves, ...; a stride near
+// the golden ratio of n_regions, coprime to it, scatters neighbouring image
+// areas over different waves.
 pt::Regions regions_for(const pt_renderer *r, size_t n_items, uint32_t row_in, int row_out, uint32_t *counts = nullptr)
 {
     if (!counts) counts = r->d_counts;
