@@ -37,6 +37,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (spec)
 VALU_PEAK_TFLOPS = 157.3   # FP32 vector peak (spec, FMA = 2 flops)
+# The intersection and shading arithmetic is compiled without contraction (one rounding per operation is the
+# parity contract), so a multiply and an add are two instructions: the ceiling such code can reach is half the spec.
+VALU_PEAK_UNCONTRACTED_TFLOPS = VALU_PEAK_TFLOPS / 2
+# Algorithmic flops per work item: a node step tests two boxes (2 x (6 fma-equivalents + 5 min/max) = 44), the
+# triangle test of pathtracer.frag.glsl:393-415 with n and dot(n, v0) hoisted is 85, finishing a segment (light
+# test, hit point) 60, one BSDF sample with its frame, barycentrics and throughput update about 400 (the mean
+# over the three lobes of frag:706-837), making a primary ray 60.
+FLOPS_PER_NODE, FLOPS_PER_TRIANGLE, FLOPS_PER_SEGMENT, FLOPS_PER_SHADED_HIT, FLOPS_PER_PATH = 44.0, 85.0, 60.0, 400.0, 60.0
 # VALU lane-operations per second the chip can issue: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz
 VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 
@@ -74,6 +82,9 @@ def parse_args():
                    help="skip the pass that times every kernel alone on one stream (profiling runs: every "
                         "launch of the run is then of the overlapped kind)")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary Veggie.obj measurement")
+    p.add_argument("--native-reduce", action="store_true",
+                   help="make the process group and the library's RCCL communicator even for one rank (what a "
+                        "launch under torch.distributed.run does by itself)")
     return p.parse_args()
 
 
@@ -101,6 +112,7 @@ class Reducer:
 
         self.pt, self.kind = pt, "rccl (pt_reduce_sum)"
         self.comm = ptd.native_comm(rank, world, device)
+        self.libraries = pt.comm_runtime_paths()  # which HIP runtime and which RCCL the reduce runs on
 
     def __call__(self, r):
         self.pt.reduce_sum([r], [self.comm], 0)
@@ -229,7 +241,8 @@ def main():
         raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} ranks but WORLD_SIZE is {world}; launch it as\n"
                          f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
                          f"--master-port 29500 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
-    distributed = world > 1
+    # one rank started by the launcher goes the whole multi-rank way too (process group, communicator, reduce)
+    distributed = world > 1 or args.native_reduce or "TORCHELASTIC_RUN_ID" in os.environ
     dist = None
     # Rehearsal on a one-GPU box: every rank on GPU 0 (RCCL refuses two ranks on one device, so the sums are
     # combined on the host through gloo).  Exercises the multi-rank control flow only; its numbers mean nothing.
@@ -238,6 +251,7 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         # torch.distributed is the control plane only (communicator id, barrier, max over ranks of the time):
         # gloo on the host; the data path is the library's own RCCL reduce.
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -345,9 +359,6 @@ def main():
         kernels = kernel_table(prof)
         alone = kernel_table(prof_alone) if prof_alone else None
         dom = max(("extend", "shade", "bounces"), key=lambda n: kernels[n]["ms_total"])
-        hbm_achieved = kernels[dom]["achieved_GBs"]
-        # counted work for the flop view: box tests ~ 2 x 17 flops per node, triangle test ~ 85 flops
-        flops = prof["nodes_visited"] * 44.0 + prof["tris_tested"] * 85.0 + seg * 60.0
         # Counters of the same command under rocprofv3 --pmc (separate passes, FETCH_SIZE doubled for gfx950),
         # kept with the profile summaries: HBM bytes per launch, VALU issue utilisation, active lanes.
         pmc, traffic = {}, None
@@ -366,42 +377,60 @@ def main():
                 traffic = pmc[dom]["hbm_read_bytes_per_launch"] + pmc[dom].get("hbm_write_bytes_per_launch", 0.0)
         occupancy = {"shade_lane_fill": prof["hits_shaded"] / max(1, 64 * prof["shade_batches"]),
                      "extend_lanes_holding_a_ray": prof["diag_lanes"]}
-        # What binds the dominant kernel.  The traversal kernel is bound by VALU issue: the figure of merit is
-        # the share of the chip's VALU lane-slots that do work = (share of issue cycles with a VALU instruction
-        # in flight, from the committed counters, rescaled to the launch duration measured here) x (active
-        # lanes per instruction / 64).  The HBM view of the same kernel is kept beside it.
+
+        # ---- the dominant kernel against its two rooflines.
+        # Work of ONE launch = the algorithmic bytes / flops per work item (the constants at the top of this file)
+        # x the work items the kernels counted, / launches.  Duration = the kernel's average launch with the GPU
+        # to itself (HIP events on its stream, one batch at a time); with two batches in flight a launch's
+        # duration includes what it shares with the other batch's kernels and is not exclusive time.
+        launches = max(1, kernels[dom]["launches"])
+        flop_terms = {
+            "nodes": prof["nodes_visited"] * FLOPS_PER_NODE, "triangle_tests": prof["tris_tested"] * FLOPS_PER_TRIANGLE,
+            "segments": seg * FLOPS_PER_SEGMENT, "shaded_hits": prof["hits_shaded"] * FLOPS_PER_SHADED_HIT,
+            "primary_rays": prof["paths"] * FLOPS_PER_PATH}
+        in_kernel = {"extend": ("nodes", "triangle_tests", "segments"), "shade": ("shaded_hits",),
+                     "bounces": ("nodes", "triangle_tests", "segments", "shaded_hits", "primary_rays")}[dom]
+        flops_per_launch = sum(flop_terms[k] for k in in_kernel) / launches
+        bytes_per_launch = kernels[dom]["algorithmic_bytes"] / launches
+        exclusive_ms = alone[dom]["avg_launch_ms"] if alone and alone[dom]["launches"] else kernels[dom]["avg_launch_ms"]
+        hbm_achieved = bytes_per_launch / max(exclusive_ms, 1e-9) / 1e6   # GB/s
+        valu_achieved = flops_per_launch / max(exclusive_ms, 1e-9) / 1e9  # TFLOP/s
+        hbm_view = {"achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
+                    "bytes_per_launch": bytes_per_launch}
+        valu_view = {"achieved": valu_achieved, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_achieved / VALU_PEAK_TFLOPS,
+                     "peak_uncontracted": VALU_PEAK_UNCONTRACTED_TFLOPS, "frac_uncontracted": valu_achieved / VALU_PEAK_UNCONTRACTED_TFLOPS,
+                     "flops_per_launch": flops_per_launch,
+                     "flops_per_path": {k: flop_terms[k] / max(1, prof["paths"]) for k in in_kernel}}
+        nearer = "hbm" if hbm_view["frac"] >= valu_view["frac"] else "valu_fp32"
+        top = hbm_view if nearer == "hbm" else valu_view
+        # Why the kernel sits below both: it is bound by VALU *issue* with part of every instruction masked off
+        # (while-while traversal of incoherent rays diverges inside the wave).  Share of issue cycles with a VALU
+        # instruction in flight and active lanes per instruction come from the committed counter file, the
+        # first rescaled to the launch duration measured here; their product is the share of the chip's VALU
+        # lane-slots doing work -- a utilisation, not a roofline fraction (useless instructions would raise it).
         m = pmc.get(dom, {})
-        live_alone_ms = alone[dom]["avg_launch_ms"] if alone else None
-        if "valu_issue_utilisation" in m and "active_lanes_per_valu_instruction" in m and live_alone_ms:
-            issue = m["valu_issue_utilisation"] * (m["avg_launch_us"] / 1e3) / live_alone_ms  # same instructions, today's duration
+        gap = None
+        if "valu_issue_utilisation" in m and "active_lanes_per_valu_instruction" in m:
+            issue = m["valu_issue_utilisation"] * (m["avg_launch_us"] / 1e3) / max(exclusive_ms, 1e-9)
             lanes = m["active_lanes_per_valu_instruction"]
-            bound = {"bound": "valu_issue", "achieved": issue * lanes / 64.0 * VALU_PEAK_TLANEOPS, "peak": VALU_PEAK_TLANEOPS,
-                     "unit": "T lane-ops/s", "frac": issue * lanes / 64.0,
-                     "valu_issue_utilisation": issue, "active_lanes_per_valu_instruction": lanes,
-                     "note": "kernel alone on the GPU; counters from " + os.path.relpath(pmc_file, ROOT)}
-        else:
-            bound = {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS,
-                     "note": "no committed counter file for this workload: HBM view only"}
-        roofline = {"kernel": dom, **bound, "traffic": traffic,
-                    "hbm_achieved_GBs": hbm_achieved, "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
+            gap = {"valu_issue_utilisation": issue, "lanes_active_of_64": lanes, "valu_lane_utilisation": issue * lanes / 64.0,
+                   "valu_lane_ops_peak_T_per_s": VALU_PEAK_TLANEOPS,
+                   "reading": f"{issue:.0%} of SIMD issue cycles carry a VALU instruction, {lanes:.1f} of 64 lanes active in it: "
+                              f"{1.0 - lanes / 64.0:.0%} of every issued vector instruction is masked off by divergence",
+                   "counters_from": os.path.relpath(pmc_file, ROOT)}
+        roofline = {"kernel": dom, "bound": nearer, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+                    "frac": top["frac"], "traffic": traffic,
+                    "definition": "algorithmic bytes (flops) of one launch / the launch's duration with the GPU to itself / peak; "
+                                  "`bound` names the roofline the kernel is nearer to",
+                    "avg_launch_ms": exclusive_ms, "avg_launch_ms_two_batches_in_flight": kernels[dom]["avg_launch_ms"],
+                    "hbm": hbm_view, "valu_fp32": valu_view, "gap": gap,
                     "pmc": {"source": os.path.relpath(pmc_file, ROOT) if pmc else None, **pmc},
                     "lane_occupancy": occupancy,
-                    "avg_launch_ms": kernels[dom]["avg_launch_ms"],
-                    "bytes_per_launch": kernels[dom]["algorithmic_bytes"] / max(1, kernels[dom]["launches"]),
-                    # The timed run keeps two batches in flight on two streams, so a launch above shares the GPU
-                    # with the other batch's kernels.  One batch at a time (pt_config.batch_streams = 1):
-                    "alone": {"avg_launch_ms": alone[dom]["avg_launch_ms"], "hbm_achieved_GBs": alone[dom]["achieved_GBs"],
-                              "hbm_frac": alone[dom]["achieved_GBs"] / HBM_PEAK_GBS, "kernels": alone} if alone else None,
+                    # every kernel of the timed configuration (launches overlap) and with one batch at a time
+                    "kernels": kernels, "alone": alone,
                     # the timed run puts all bounces of a batch in one launch; the same work as one launch per kernel
                     # and bounce, one batch at a time:
-                    "as_separate_launches": kernel_table(prof_sep) if prof_sep else None,
-                    # counted traversal work (box and triangle tests) over the time of the kernel(s) that did it
-                    "flop_view": (lambda ms: {"extend_counted_gflop": flops / 1e9,
-                                              "extend_tflops": flops / max(ms, 1e-9) / 1e9,
-                                              "peak_tflops": VALU_PEAK_TFLOPS,
-                                              "frac": flops / max(ms, 1e-9) / 1e9 / VALU_PEAK_TFLOPS})(
-                        prof["ms_extend"] + prof["ms_bounces"]),
-                    "kernels": kernels}
+                    "as_separate_launches": kernel_table(prof_sep) if prof_sep else None}
         # The whole pipeline against HBM: algorithmic bytes of all kernels of a step over the step's wall time.
         bytes_per_path = sum(k["algorithmic_bytes"] for k in kernels.values()) / max(1, prof["paths"])
         pipeline_gbs = bytes_per_path * (total_paths / world) / dt / 1e9
@@ -419,7 +448,8 @@ def main():
                                       f"{args.spp_per_step} spp per step per GPU")
                                    + f", batches of {args.batch_spp} spp, default camera and light",
                        "paths_per_step": n_pixels * spp_all_ranks, "parallelism": f"sample-partition x{world}",
-                       "reduce": reducer.kind if reducer else None},
+                       "reduce": reducer.kind if reducer else None,
+                       "reduce_libraries": getattr(reducer, "libraries", None)},
             "msegments_per_s": value * st["segments"] / max(1, st["paths"]),
             "segments_per_path": st["segments"] / max(1, st["paths"]),
             "gates": gates,

@@ -216,8 +216,9 @@ int pt_read_radiance(pt_renderer *r, float *rgba_host);
 /* post.frag:11-15 (Reinhard then gamma 1/2.2) on the mean, as 8-bit RGB,
  * row 0 = TOP row (image-file order). */
 int pt_read_tonemapped(pt_renderer *r, uint8_t *rgb_host);
-/* pt_read_tonemapped for callers that cannot allocate device memory (code under HIP graph capture, tight
- * preview loops, harnesses that forbid hipMalloc): the same kernel, the same bytes, but the 8-bit image is
+/* pt_read_tonemapped for callers that cannot allocate device memory (tight preview loops, harnesses that
+ * forbid hipMalloc / hipFree between frames; not for use inside a HIP graph capture: like every readback it
+ * synchronises the renderer's streams and copies to pageable host memory): the same kernel, the same bytes, but the 8-bit image is
  * staged in a device array that is part of the library (one copy per GPU, 10.5 MiB, held until the process
  * ends) instead of a buffer allocated and freed per call.  No counterpart in the reference.  Images of more
  * than 2560 x 1440 = 3 686 400 pixels are refused with PT_ERR_INVALID.  All calls on one GPU share that
@@ -270,6 +271,12 @@ int pt_comm_create(const uint8_t id[PT_COMM_ID_BYTES], uint32_t rank, uint32_t w
 /* n communicators, rank k on devices[k], written to out[0..n-1].               ncclCommInitAll  */
 int pt_comm_create_all(const int32_t *devices, uint32_t n, pt_comm **out);
 void pt_comm_destroy(pt_comm *comm);
+/* Which shared objects the reduce runs on, as text "hip=<path>\nrccl=<path>\nrccl_hip=<path>": the HIP runtime
+ * this library is bound to, the RCCL it loaded (the copy beside that runtime when there is one), and the HIP
+ * runtime that RCCL calls into.  A process may hold two HIP runtimes (a Python wheel's bundled copy and the
+ * system's); the reduce is only meaningful when `hip` and `rccl_hip` name the same file.  Diagnostic; no
+ * reference counterpart. */
+int pt_comm_runtime_paths(char *out, size_t bytes);
 /* ncclReduce(sum, float) of the renderers' sum buffers (width*height*4 floats, the alpha lane carrying the
  * sample counts) into rank `root`'s, in place, enqueued on each renderer's own stream after its pending
  * batches: asynchronous, pt_synchronize or any readback waits for it.  n = 1 in a process that drives one

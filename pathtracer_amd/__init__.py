@@ -181,6 +181,7 @@ _SIGNATURES = {
     "pt_comm_create": (C.c_int, [_u8p, C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(_vp)]),
     "pt_comm_create_all": (C.c_int, [_i32p, C.c_uint32, C.POINTER(_vp)]),
     "pt_comm_destroy": (None, [_vp]),
+    "pt_comm_runtime_paths": (C.c_int, [C.c_char_p, C.c_size_t]),
     "pt_reduce_sum": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.c_uint32, C.c_uint32]),
     "pt_sum_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "pt_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
@@ -382,6 +383,14 @@ def comm_unique_id() -> bytes:
     buf = np.zeros(COMM_ID_BYTES, np.uint8)
     _check(_lib.pt_comm_unique_id(_ptr(buf, _u8p)))
     return buf.tobytes()
+
+
+def comm_runtime_paths() -> dict:
+    """{"hip": ..., "rccl": ..., "rccl_hip": ...}: the HIP runtime the library is bound to, the RCCL it loaded
+    and the HIP runtime that RCCL calls into (pt_comm_runtime_paths)."""
+    buf = C.create_string_buffer(4096)
+    _check(_lib.pt_comm_runtime_paths(buf, len(buf)))
+    return dict(line.split("=", 1) for line in buf.value.decode().splitlines())
 
 
 class Comm:

@@ -9,7 +9,9 @@
 //             [--no-light]
 //             [--resume state.bin] [--save-state state.bin] [--checkpoint-every n]
 //             [--preview-every n]   rewrite --out after every n samples per pixel (a progressive preview)
-//             [--scan] [--bvh host|device] [--out image.ppm] [--pfm radiance.pfm]
+//             [--scan] [--bvh host|device] [--out image.ppm | image.png] [--pfm radiance.pfm]
+//                                   (--out: a name ending in .png is written as PNG, the format of the reference's
+//                                   published output/*.png; anything else as binary PPM)
 //             [--gpus n]            sample-partition the render over n GPUs of this machine: GPU g renders
 //                                   iterations g, g + n, ...; one RCCL reduce into GPU 0 before an image is
 //                                   written (not with --resume / --save-state)
@@ -35,6 +37,98 @@ bool write_ppm(const std::string &path, const std::vector<uint8_t> &rgb, uint32_
     bool ok = std::fwrite(rgb.data(), 1, rgb.size(), f) == rgb.size();
     std::fclose(f);
     return ok;
+}
+
+// PNG, 8-bit RGB, rows top-down as the tone-mapped image has them.  The pixel data go into the zlib stream as
+// stored (uncompressed) deflate blocks: no compression library is needed, and a file of this kind is read by
+// every PNG decoder.  Chunks carry a CRC-32 (polynomial 0xEDB88320), the zlib stream ends with the Adler-32 of the
+// raw data.
+uint32_t crc32_update(uint32_t crc, const uint8_t *data, size_t n)
+{
+    static uint32_t table[256];
+    static bool made = false;
+    if (!made) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        made = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ data[i]) & 0xFFu] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<uint8_t> &v, uint32_t x)
+{
+    for (int s = 24; s >= 0; s -= 8) v.push_back(static_cast<uint8_t>(x >> s));
+}
+bool write_png_chunk(FILE *f, const char type[4], const std::vector<uint8_t> &data)
+{
+    std::vector<uint8_t> head;
+    put_be32(head, static_cast<uint32_t>(data.size()));
+    head.insert(head.end(), type, type + 4);
+    uint32_t crc = crc32_update(0xFFFFFFFFu, head.data() + 4, 4);
+    crc = crc32_update(crc, data.data(), data.size()) ^ 0xFFFFFFFFu;
+    std::vector<uint8_t> tail;
+    put_be32(tail, crc);
+    return std::fwrite(head.data(), 1, head.size(), f) == head.size() &&
+           (data.empty() || std::fwrite(data.data(), 1, data.size(), f) == data.size()) &&
+           std::fwrite(tail.data(), 1, 4, f) == 4;
+}
+bool write_png(const std::string &path, const std::vector<uint8_t> &rgb, uint32_t w, uint32_t h)
+{
+    if (w == 0 || h == 0 || rgb.size() != static_cast<size_t>(w) * h * 3) return false;
+    // scanlines, each led by its filter byte (0 = none)
+    std::vector<uint8_t> raw;
+    raw.reserve((static_cast<size_t>(w) * 3 + 1) * h);
+    for (uint32_t y = 0; y < h; ++y) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb.begin() + static_cast<size_t>(y) * w * 3, rgb.begin() + static_cast<size_t>(y + 1) * w * 3);
+    }
+    uint32_t a = 1, b = 0;  // Adler-32
+    for (size_t i = 0; i < raw.size();) {
+        const size_t n = std::min<size_t>(5552, raw.size() - i);  // the sums cannot overflow 32 bits within 5552 bytes
+        for (size_t k = 0; k < n; ++k) {
+            a += raw[i + k];
+            b += a;
+        }
+        a %= 65521u;
+        b %= 65521u;
+        i += n;
+    }
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78);  // deflate, 32 K window
+    z.push_back(0x01);  // no preset dictionary, check bits: 0x7801 is a multiple of 31
+    for (size_t i = 0; i < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - i);
+        z.push_back(i + n == raw.size() ? 1 : 0);  // BFINAL, BTYPE = 00 (stored)
+        z.push_back(static_cast<uint8_t>(n & 0xFF));
+        z.push_back(static_cast<uint8_t>(n >> 8));
+        z.push_back(static_cast<uint8_t>(~n & 0xFF));
+        z.push_back(static_cast<uint8_t>((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + i, raw.begin() + i + n);
+        i += n;
+    }
+    put_be32(z, (b << 16) | a);
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    static const uint8_t signature[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, w);
+    put_be32(ihdr, h);
+    ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});  // 8 bits per channel, colour type 2 (RGB), deflate, adaptive filtering, no interlace
+    bool ok = std::fwrite(signature, 1, 8, f) == 8 && write_png_chunk(f, "IHDR", ihdr) && write_png_chunk(f, "IDAT", z) &&
+              write_png_chunk(f, "IEND", {});
+    ok = (std::fclose(f) == 0) && ok;
+    return ok;
+}
+
+// The tone-mapped image by the name's extension: .png as PNG, anything else as binary PPM.
+bool write_image(const std::string &path, const std::vector<uint8_t> &rgb, uint32_t w, uint32_t h)
+{
+    const bool png = path.size() >= 4 && (path.compare(path.size() - 4, 4, ".png") == 0 || path.compare(path.size() - 4, 4, ".PNG") == 0);
+    return png ? write_png(path, rgb, w, h) : write_ppm(path, rgb, w, h);
 }
 
 // PFM stores rows bottom-up, which is the renderer's own row order.
@@ -156,7 +250,7 @@ int main(int argc, char **argv)
                 done += n;
                 if (preview_every && done < spp) {
                     multi.reduce();
-                    if (!write_ppm(out, multi.root().tonemapped(), width, height)) std::fprintf(stderr, "cannot write %s\n", out.c_str());
+                    if (!write_image(out, multi.root().tonemapped(), width, height)) std::fprintf(stderr, "cannot write %s\n", out.c_str());
                     std::printf("preview at %u spp\n", done);
                 }
             }
@@ -172,7 +266,7 @@ int main(int argc, char **argv)
             std::printf("%zu triangles, %ux%u, %u spp on %u GPUs, depth %u: %.3f s, %.1f Mpaths/s, %.2f segments/path\n",
                         scene.m_indices.size(), width, height, done, gpus, depth, secs, static_cast<double>(paths) / secs / 1e6,
                         paths ? static_cast<double>(segments) / static_cast<double>(paths) : 0.0);
-            if (!write_ppm(out, multi.root().tonemapped(), width, height)) {
+            if (!write_image(out, multi.root().tonemapped(), width, height)) {
                 std::fprintf(stderr, "cannot write %s\n", out.c_str());
                 return 1;
             }
@@ -199,7 +293,7 @@ int main(int argc, char **argv)
             done += n;
             if (checkpoint_every && done % checkpoint_every == 0 && !save_state.empty()) renderer.saveState(save_state);
             if (preview_every && done % preview_every == 0 && done < spp) {
-                if (!write_ppm(out, renderer.tonemapped(), width, height)) std::fprintf(stderr, "cannot write %s\n", out.c_str());
+                if (!write_image(out, renderer.tonemapped(), width, height)) std::fprintf(stderr, "cannot write %s\n", out.c_str());
                 std::printf("preview at %u spp\n", done);
             }
         }
@@ -213,7 +307,7 @@ int main(int argc, char **argv)
                     scene.m_indices.size(), st.n_nodes, st.bvh_depth, st.bvh_builder ? "device" : "host", st.bvh_build_ms,
                     width, height, done, depth, secs,
                     new_paths / secs / 1e6, st.paths > 0 ? static_cast<double>(st.segments) / static_cast<double>(st.paths) : 0.0);
-        if (!write_ppm(out, renderer.tonemapped(), width, height)) {
+        if (!write_image(out, renderer.tonemapped(), width, height)) {
             std::fprintf(stderr, "cannot write %s\n", out.c_str());
             return 1;
         }

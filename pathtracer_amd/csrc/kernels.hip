@@ -1582,27 +1582,36 @@ namespace {
 // size), so no block waits for another to retire, and never more waves than
 // there are regions to hand out.
 // Blocks of `kernel` (block size `block`, `lds_bytes` of dynamic LDS) a CU keeps resident.  The runtime's
-// occupancy query is asked once per (kernel, LDS size) and process: it costs more than a kernel launch, and
-// the reference's usage pattern is one sample per draw (renderer.cpp:124-150), i.e. many small launches.
+// occupancy query is asked once per (device, kernel, LDS size) and process: it costs more than a kernel launch,
+// and the reference's usage pattern is one sample per draw (renderer.cpp:124-150), i.e. many small launches.
+// The device is part of the key because the dynamic-LDS limit raised below is an attribute of the kernel ON
+// the current device: a process that drives several GPUs has to raise it on each of them.
 int blocks_per_cu(const void *kernel, int block, size_t lds_bytes)
 {
     struct Key {
+        int device;
         const void *kernel;
         size_t lds;
         int block;
         bool operator<(const Key &o) const
         {
+            if (device != o.device) return device < o.device;
             return kernel != o.kernel ? kernel < o.kernel : (lds != o.lds ? lds < o.lds : block < o.block);
         }
     };
     static std::mutex mutex;
     static std::map<Key, int> cache;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
     std::lock_guard<std::mutex> lock(mutex);
-    const Key key{kernel, lds_bytes, block};
+    const Key key{device, kernel, lds_bytes, block};
     const auto it = cache.find(key);
     if (it != cache.end()) return it->second;
-    if (lds_bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)) != hipSuccess) {
+        // the launch that follows would fail with "invalid value"; leave the error for the caller's hipGetLastError
+        return 1;
+    }
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
     cache[key] = per_cu;
@@ -1735,6 +1744,8 @@ using ExtendKernel = void (*)(SceneView, Regions, PathQueue, float4 *, float4 *,
 template <int BLOCK, int L>
 ExtendKernel extend_kernel_for(bool counting, bool exact, bool render, bool use_lt)
 {
+    if (exact && render && counting && use_lt) return k_extend_bvh<BLOCK, true, true, L, true, true>;
+    if (exact && render && counting) return k_extend_bvh<BLOCK, true, true, L, true, false>;
     if (exact && render && use_lt) return k_extend_bvh<BLOCK, false, true, L, true, true>;
     if (exact && render) return k_extend_bvh<BLOCK, false, true, L, true, false>;
     if (exact) return k_extend_bvh<BLOCK, false, true, L, false, false>;

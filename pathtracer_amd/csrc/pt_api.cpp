@@ -1334,7 +1334,15 @@ int pt_load_state(pt_renderer *r, const char *path)
     StateHeader h;
     const size_t n = static_cast<size_t>(r->width) * r->height * 4;
     std::vector<float> sum(n);
-    bool ok = std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "PTAMDST2", 8) == 0;
+    bool ok = std::fread(&h, sizeof(h), 1, f) == 1;
+    if (ok && std::memcmp(h.magic, "PTAMDST1", 8) == 0) {
+        // Files of the first format carry no counters and a scene hash computed byte by byte, which this build
+        // cannot check against its own (word-wise) hash: refused by name rather than as a damaged file.
+        std::fclose(f);
+        return fail(PT_ERR_STATE, std::string("pt_load_state: ") + path +
+                                      " is a version-1 state file (PTAMDST1); this build reads version 2 only -- render again and save");
+    }
+    ok = ok && std::memcmp(h.magic, "PTAMDST2", 8) == 0;
     const bool fits = ok && h.width == r->width && h.height == r->height;
     ok = fits && std::fread(sum.data(), sizeof(float), n, f) == n && std::fgetc(f) == EOF;
     std::fclose(f);

@@ -7,7 +7,10 @@
 // (pt_set_partition), and nothing is exchanged until this reduce.
 //
 // RCCL is loaded when the first communicator is made (dlopen), so a single-GPU user of the library never
-// needs it, and a process that already has an RCCL loaded (e.g. PyTorch's) uses that same copy.
+// needs it.  Which copy: the one that lies beside the HIP runtime this library is itself bound to.  A process
+// may hold two HIP runtimes (a Python wheel that bundles its own libamdhip64 and librccl next to the system's
+// ROCm); streams and device pointers of one are meaningless to the other, so the RCCL that reduces this
+// library's buffers on this library's streams has to be the one linked against the same runtime.
 #include "../../include/pathtracer_amd.h"
 
 #include <dlfcn.h>
@@ -44,16 +47,37 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    std::string why;  // why loading failed
+    std::string why;   // why loading failed
+    std::string path;  // where the loaded library lies
 };
+
+// Directory of the shared object that holds `symbol` (with a trailing slash), empty when unknown.
+std::string directory_of(const void *symbol)
+{
+    Dl_info info;
+    if (!dladdr(symbol, &info) || !info.dli_fname) return std::string();
+    const std::string file(info.dli_fname);
+    const size_t slash = file.rfind('/');
+    return slash == std::string::npos ? std::string() : file.substr(0, slash + 1);
+}
+std::string file_of(const void *symbol)
+{
+    Dl_info info;
+    return (dladdr(symbol, &info) && info.dli_fname) ? std::string(info.dli_fname) : std::string("?");
+}
 
 Rccl &rccl_lib()
 {
     static Rccl lib;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // beside the HIP runtime hipGetDevice resolves to from here, then by soname, then the usual place
+        const std::string beside = directory_of(reinterpret_cast<const void *>(&hipGetDevice));
+        std::vector<std::string> names;
+        if (!beside.empty()) names.insert(names.end(), {beside + "librccl.so.1", beside + "librccl.so"});
+        names.insert(names.end(), {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"});
+        for (const std::string &name : names) {
+            lib.handle = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
             if (lib.handle) break;
             const char *e = dlerror();
             lib.why = e ? e : "dlopen failed";
@@ -79,7 +103,9 @@ Rccl &rccl_lib()
         if (!ok) {
             dlclose(lib.handle);
             lib.handle = nullptr;
+            return;
         }
+        lib.path = file_of(reinterpret_cast<const void *>(lib.Reduce));
     });
     return lib;
 }
@@ -148,13 +174,39 @@ int pt_comm_create_all(const int32_t *devices, uint32_t n, pt_comm **out)
     const ncclResult_t e = lib->CommInitAll(comms.data(), static_cast<int>(n), devs.data());
     if (e != ncclSuccess) return nccl_fail(lib, "ncclCommInitAll", e);
     for (uint32_t k = 0; k < n; ++k) {
-        pt_comm *c = new pt_comm();
+        pt_comm *c = new (std::nothrow) pt_comm();
+        if (!c) {
+            // nothing half-made is handed out: the wrappers so far and every communicator go again
+            for (uint32_t j = 0; j < k; ++j) {
+                delete out[j];
+                out[j] = nullptr;
+            }
+            for (uint32_t j = 0; j < n; ++j) {
+                (void)hipSetDevice(devs[j]);
+                (void)lib->CommDestroy(comms[j]);
+            }
+            return set_error(PT_ERR_INVALID, "out of memory");
+        }
         c->comm = comms[k];
         c->device = devs[k];
         c->rank = k;
         c->world = n;
         out[k] = c;
     }
+    return PT_OK;
+}
+
+int pt_comm_runtime_paths(char *out, size_t bytes)
+{
+    if (!out || bytes == 0) return set_error(PT_ERR_INVALID, "pt_comm_runtime_paths: null argument");
+    Rccl *lib = rccl();
+    if (!lib) return PT_ERR_DEVICE;
+    // the HIP runtime RCCL calls into, as seen from inside RCCL: the object that holds the hipGetDevice it resolves to
+    std::string rccl_hip = "?";
+    if (void *sym = dlsym(lib->handle, "hipGetDevice")) rccl_hip = file_of(sym);
+    const std::string text = "hip=" + file_of(reinterpret_cast<const void *>(&hipGetDevice)) + "\nrccl=" + lib->path + "\nrccl_hip=" + rccl_hip;
+    std::strncpy(out, text.c_str(), bytes - 1);
+    out[bytes - 1] = '\0';
     return PT_OK;
 }
 
@@ -183,15 +235,31 @@ int pt_reduce_sum(pt_renderer *const *renderers, pt_comm *const *comms, uint32_t
             return set_error(PT_ERR_INVALID, "pt_reduce_sum: renderer and communicator are on different devices");
         if (bufs[k].count != bufs[0].count) return set_error(PT_ERR_INVALID, "pt_reduce_sum: the renderers' image sizes differ");
     }
+    if (n > 1) {
+        // Several ranks driven from this one call: they must be ALL ranks of one communicator, each once.  A rank
+        // left out would never issue its part of the collective and the others would wait for it on their streams.
+        std::vector<bool> seen(n, false);
+        for (uint32_t k = 0; k < n; ++k) {
+            if (comms[k]->world != n)
+                return set_error(PT_ERR_INVALID, "pt_reduce_sum: n renderers need the n communicators of one pt_comm_create_all");
+            if (comms[k]->rank >= n || seen[comms[k]->rank]) return set_error(PT_ERR_INVALID, "pt_reduce_sum: ranks must be 0..n-1, each once");
+            seen[comms[k]->rank] = true;
+        }
+    }
     // One collective: in a process that drives several GPUs the calls of all its ranks are issued as a group.
     ncclResult_t e = n > 1 ? lib->GroupStart() : ncclSuccess;
     if (e != ncclSuccess) return nccl_fail(lib, "ncclGroupStart", e);
-    for (uint32_t k = 0; k < n && e == ncclSuccess; ++k) {
-        if (hipSetDevice(bufs[k].device) != hipSuccess) return set_error(PT_ERR_DEVICE, "pt_reduce_sum: hipSetDevice failed");
+    bool device_failed = false;
+    for (uint32_t k = 0; k < n && e == ncclSuccess && !device_failed; ++k) {
+        if (hipSetDevice(bufs[k].device) != hipSuccess) {
+            device_failed = true;  // the group opened above is still closed below
+            break;
+        }
         e = lib->Reduce(bufs[k].data, bufs[k].data, bufs[k].count, ncclFloat, ncclSum, static_cast<int>(root), comms[k]->comm,
                         bufs[k].stream);
     }
     const ncclResult_t e2 = n > 1 ? lib->GroupEnd() : ncclSuccess;
+    if (device_failed) return set_error(PT_ERR_DEVICE, "pt_reduce_sum: hipSetDevice failed");
     if (e != ncclSuccess) return nccl_fail(lib, "ncclReduce", e);
     if (e2 != ncclSuccess) return nccl_fail(lib, "ncclGroupEnd", e2);
     // The samples of the other ranks now live in the root's buffer: their own sums start again from zero (their

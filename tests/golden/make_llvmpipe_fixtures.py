@@ -67,8 +67,25 @@ def ids_fixture(name, w, h, iteration, full, cam=None, tag=""):
           "miss", int((ids == -1).sum()), os.path.getsize(path), flush=True)
 
 
+def image_fixture(name, w, h, spp, depth):
+    """Float-accumulated image (non-finite samples zeroed) of iterations 0..spp-1.  Stored as float16 plus, in
+    full precision, the few values float16 does not hold to 1e-3 (large or tiny samples)."""
+    a, c = scene_and_cam(name, w, h)
+    t0 = time.time()
+    img, secs = rr.run(a, c, w, h, "float0", spp, depth)
+    rgb = img[..., :3].astype(np.float32)
+    half = rgb.astype(np.float16)
+    back = half.astype(np.float32)
+    odd = np.flatnonzero(~(np.abs(back - rgb) <= 1e-3 * np.abs(rgb)).ravel())
+    path = os.path.join(OUT, f"image_{name}_{w}x{h}_spp{spp}_depth{depth}.npz")
+    np.savez_compressed(path, mean_rgb_f16=half, exact_index=odd.astype(np.int64), exact_value=rgb.ravel()[odd],
+                        spp=np.int32(spp), depth=np.int32(depth), llvmpipe_seconds=np.float64(secs))
+    print(name, w, h, spp, depth, "mean", rgb.mean(axis=(0, 1), dtype=np.float64), "exact", odd.size,
+          "%.1fs" % (time.time() - t0), os.path.getsize(path), flush=True)
+
+
 def main():
-    what = sys.argv[1] if len(sys.argv) > 1 else "ids"
+    what =sys.argv[1] if len(sys.argv) > 1 else "ids"
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(HERE, "scenes", "*.npz")))
     if what == "ids":
         for n in names:
@@ -110,6 +127,14 @@ def main():
         np.savez_compressed(os.path.join(OUT, "rgba8_Box_256x256_spp64_depth10.npz"), rgba8=img, spp=np.int32(64),
                             depth=np.int32(10))
         print("rgba8 Box mean", img[..., :3].mean(axis=(0, 1)) / 255.0, flush=True)
+    elif what == "images_1080p":
+        # float images at the benchmark size and depth (iterations 0..15): Box ~1 min, Veggie ~6 min on 8 cores
+        for n in sys.argv[2:] or ("Box", "Veggie"):
+            image_fixture(n, 1920, 1080, 16, 8)
+    elif what == "image_no_usemtl":
+        # cube.obj has no usemtl: its faces carry material id 0xFFFFFFFF (scene.h:133), and what such a surface
+        # scatters is whatever the driver returns for the out-of-range buffer-texture fetches of frag:105-126
+        image_fixture("cube", 128, 128, 64, 8)
     elif what == "timing":
         rows = []
         for n, w, h, spp, depth in [("Box", 512, 512, 64, 5), ("Box", 512, 512, 16, 10), ("Box", 256, 256, 8, 8),

@@ -102,3 +102,51 @@ def test_cli_lights_camera_checkpoint_resume(tmp_path):
     bad = subprocess.run([EXE, "--scene", "room.obj", "--mtl-root", "./", "--width", "32", "--height", "32", "--spp", "2",
                           "--resume", "s.bin"], cwd=tmp_path, capture_output=True, text=True, timeout=240)
     assert bad.returncode != 0 and "pt_load_state" in bad.stderr
+
+
+def _read_png_rgb8(path):
+    """A minimal PNG reader of our own (8-bit RGB, no interlace; filter type per scanline honoured for type 0
+    only), with every chunk's CRC and the zlib stream's Adler-32 checked by zlib."""
+    import struct
+    import zlib
+
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, chunks = 8, []
+    while at < len(data):
+        n, kind = struct.unpack(">I4s", data[at:at + 8])
+        body = data[at + 8:at + 8 + n]
+        (crc,) = struct.unpack(">I", data[at + 8 + n:at + 12 + n])
+        assert zlib.crc32(kind + body) & 0xFFFFFFFF == crc, f"bad CRC in {kind}"
+        chunks.append((kind, body))
+        at += 12 + n
+    assert [k for k, _ in chunks][0] == b"IHDR" and chunks[-1] == (b"IEND", b"")
+    w, h, bits, colour, comp, flt, lace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (bits, colour, comp, flt, lace) == (8, 2, 0, 0, 0)
+    raw = zlib.decompress(b"".join(b for k, b in chunks if k == b"IDAT"))  # raises on a wrong Adler-32
+    rows = np.frombuffer(raw, np.uint8).reshape(h, 1 + 3 * w)
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:].reshape(h, w, 3)
+
+
+def test_cli_writes_png(tmp_path):
+    """--out x.png: the tone-mapped image as PNG (the format of the reference's published output/*.png), the same
+    bytes as the PPM of the same render; read back with our own checker and, where installed, with PIL."""
+    if not os.path.exists(EXE):
+        pytest.fail("pathtracer_amd/pt_render is not built")
+    (tmp_path / "room.obj").write_text(ROOM)
+    (tmp_path / "room.mtl").write_text(MTL)
+    # 301 x 223: scanlines of odd length, 201 KB of pixel data = four stored deflate blocks
+    common = ["--scene", "room.obj", "--mtl-root", "./", "--width", "301", "--height", "223", "--depth", "5", "--spp", "6"]
+    _run(common + ["--out", "a.png"], tmp_path)
+    _run(common + ["--out", "a.ppm"], tmp_path)
+    with open(tmp_path / "a.ppm", "rb") as f:
+        assert f.readline() == b"P6\n" and f.readline() == b"301 223\n" and f.readline() == b"255\n"
+        ppm = np.frombuffer(f.read(), np.uint8).reshape(223, 301, 3)
+    png = _read_png_rgb8(tmp_path / "a.png")
+    assert ppm.any() and np.array_equal(png, ppm)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "a.png").convert("RGB")), ppm)
