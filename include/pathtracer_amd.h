@@ -133,6 +133,10 @@ typedef struct {
      * cover only the batches that were launched kernel by kernel. */
     double ms_bounces;
     uint64_t launches_bounces;
+    /* Primary rays that ray generation found to meet neither the scene's bounds nor a light and therefore
+     * never enqueued (they can only add zero, frag:876).  They are counted in `segments` -- every path has a
+     * first segment -- but no traversal kernel ever reads them. */
+    uint64_t primary_rays_culled;
 } pt_stats;
 
 const char *pt_last_error(void);

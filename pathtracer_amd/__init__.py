@@ -115,6 +115,7 @@ class Stats(C.Structure):
         ("reserved", C.c_uint32),
         ("ms_bounces", C.c_double),
         ("launches_bounces", C.c_uint64),
+        ("primary_rays_culled", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:

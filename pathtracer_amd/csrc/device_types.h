@@ -54,6 +54,10 @@ struct DeviceCamera {
     // Division by three run-time constants without a divide: x / d = umulhi(x, magic) >> shift for x < 2^31.
     FastDiv div_pixels, div_tiles_x, div_width;
     FastDiv div_map_units;  // valid when (map_units - 1) * map_stride < 2^31; magic = 0xFFFFFFFF says it is not
+    // Pixels (columns cull_x0..cull_x1, rows cull_y0..cull_y1, inclusive) outside of which no primary ray can meet
+    // the scene's bounds or a light: the bounding rectangle of their projections, widened by a margin (host:
+    // update_cull_window).  The whole image when the host cannot tell (geometry beside or behind the eye).
+    uint32_t cull_x0, cull_x1, cull_y0, cull_y1;
 };
 
 }  // namespace pt

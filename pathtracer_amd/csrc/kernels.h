@@ -26,9 +26,8 @@ struct SceneView {
 
 // One path queue: three 16-byte lanes per path.
 //   p0 = (origin.xyz, dir.x)  p1 = (dir.y, dir.z, seed.x, seed.y)  p2 = (throughput.rgb, sample slot)
-// (p2 is not stored for primary rays: ExtendOutput::primary_of)
 // lt: with exactly one light in the scene, the distance at which the ray meets it (frag:363-382), computed by
-// the kernel that creates the ray; < 0 when it does not.  The traversal then starts with that distance as its
+// the kernel that creates the ray; a quiet NaN when it does not (and always with another number of lights).  The traversal then starts with that distance as its
 // limit instead of testing the light when the ray finishes.
 struct PathQueue {
     float4 *p0;
@@ -83,9 +82,17 @@ struct BatchParams {
 };
 void launch_set_batch(hipStream_t s, BatchParams *params, const DeviceCamera &cam, uint32_t it_first, uint32_t sample_tag);
 
-// counts_out: n_regions live counts of bounce 0.
+// Readbacks: every pixel's ray of one iteration at the slot the slot -> pixel mapping gives it (lanes p0, p1 and
+// the light distance; no path state).  counts_out: n_regions live counts.
 void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, const BatchParams *params, uint32_t it_stride,
                    uint32_t n_iterations, PathQueue out, uint32_t *counts_out, uint32_t region_size);
+
+// The render loop's primary rays, region by region, all three lanes.  cull: rays that meet neither the scene's
+// bounds (the traversal's own first step) nor a light are not written -- they could only add zero -- and the
+// rest is packed to the front of its region; regions.counts_out receives the rays written per region,
+// culled_out the rays left out.
+void launch_raygen_regions(hipStream_t s, LaunchShape g, const SceneView &scene, const BatchParams *params, uint32_t it_stride,
+                           uint32_t n_iterations, PathQueue out, Regions regions, uint32_t *culled_out, bool cull);
 
 // Where extend puts its results.
 //  render = false: hit_list is written as a float2 array, results[slot] = (t, hit code), for every ray
@@ -102,9 +109,6 @@ struct ExtendOutput {
     bool last_segment;
     bool exact_parallel;
     const BatchParams *params = nullptr;  // the batch's block (render = true): sample tag, camera
-    // First segment of a batch made by launch_raygen: lane p2 (throughput 1, the path's own sample slot) is not
-    // stored for it but derived from the queue slot with the camera's slot -> pixel mapping.
-    bool primary = false;
     // Where the traversal kernel keeps the deep ends of its stacks when the tree is read from memory
     // (extend_stack_overflow_bytes); null: whole stacks in LDS.  One buffer per launch in flight.
     int *stack_overflow = nullptr;
@@ -131,7 +135,8 @@ struct BounceLoop {
     PathQueue q[2];    // bounce b reads q[b & 1] and writes q[(b + 1) & 1]
     float4 *hit_list;
     float4 *samples;
-    uint32_t *counts;  // rows of `pitch` entries: 0..depth rays per region and bounce, depth+1.. hits per region and bounce
+    uint32_t *counts;  // rows of `pitch` entries: 0..depth rays per region and bounce, depth+1..2*depth hits per region and
+                       // bounce, 2*depth+1 primary rays per region that ray generation did not enqueue
     uint32_t pitch, n_regions, stride, size, depth;
 };
 // Waves of k_bounces resident at once for this scene (as extend_resident_waves for the traversal kernel).
@@ -146,7 +151,7 @@ void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
                   const float4 *hit_list, PathQueue out, float4 *samples /* receives the sample of a path whose ray went non-finite */,
-                  const BatchParams *params, bool primary /* as in ExtendOutput */,
+                  const BatchParams *params,
                   bool final_bounce /* the hits of the last allowed segment: nothing survives, only non-finite samples are written */);
 
 // The sample buffer is never cleared: a path that ends on a light writes (radiance, tag) with the tag of its
@@ -155,8 +160,8 @@ void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, floa
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
                        uint32_t pitch, unsigned long long *segments_total,
                        unsigned long long *shade_totals /* [0] surface hits shaded, [1] 64-lane batches formed */,
-                       unsigned long long *nan_counter, uint8_t *rgba8 /* may be null */, const BatchParams *params,
-                       uint32_t it_stride);
+                       unsigned long long *nan_counter, unsigned long long *culled_total /* primary rays not enqueued (counts row 2*n_rows+1) */,
+                       uint8_t *rgba8 /* may be null */, const BatchParams *params, uint32_t it_stride);
 
 // hits -> int32 hit codes / t / directions in pixel order for one iteration.
 // cam: the camera whose raygen made the rays (its slot -> pixel mapping orders the output by pixel); null: rays

@@ -142,15 +142,6 @@ __device__ __forceinline__ uint32_t pixel_of_slot(const DeviceCamera &cam, uint3
     return ((ty << 3) + (in_unit >> 3)) * cam.width + (tx << 3) + (in_unit & 7u);
 }
 
-// Lane p2 of a primary ray: throughput 1 and the slot of the path's sample, iteration_in_batch * W*H + pixel.
-__device__ __forceinline__ float4 primary_p2(const DeviceCamera &cam, uint32_t slot)
-{
-    const uint32_t n_pixels = cam.width * cam.height;
-    uint32_t j;
-    const uint32_t k = div_by(slot, n_pixels, cam.div_pixels, j);
-    return make_float4(1.f, 1.f, 1.f, __uint_as_float(k * n_pixels + pixel_of_slot(cam, j)));
-}
-
 // frag:866 + frag:306-320.  Path slot i = k * (W*H) + j, j-th slot of iteration k -> pixel_of_slot.
 __global__ void __launch_bounds__(64) k_set_batch(BatchParams *params, DeviceCamera cam, uint32_t it_first, uint32_t sample_tag)
 {
@@ -173,26 +164,29 @@ __device__ __forceinline__ PrimaryFrame primary_frame(const DeviceCamera &cam)
     const f3 right = mk(cam.right[0], cam.right[1], cam.right[2]);
     return PrimaryFrame{eye, eye + fwd, (right * cam.tan_half_fov) * cam.aspect, up * cam.tan_half_fov};
 }
-// The primary ray of pixel (x, y) in iteration `iteration`, written to slot i of the queue.
-__device__ __forceinline__ void write_primary_ray(const SceneView &sc, const DeviceCamera &cam, const PrimaryFrame &f, uint32_t x,
-                                                  uint32_t y, uint32_t iteration, const PathQueue &out, uint32_t i)
+// The primary ray of pixel (x, y) in iteration `iteration` (frag:866, :306-320).
+struct PrimaryRay {
+    f3 d;
+    uint32_t sx, sy;  // the path's RNG state after the two jitter draws
+};
+__device__ __forceinline__ PrimaryRay primary_ray(const DeviceCamera &cam, const PrimaryFrame &f, uint32_t x, uint32_t y, uint32_t iteration)
 {
     const float fx = static_cast<float>(x) + 0.5f, fy = static_cast<float>(y) + 0.5f;
-    uint32_t sx = (iteration + 1u) * x;
-    uint32_t sy = (iteration + 2u) * y;
-    const float jx = rng_next(sx, sy);
-    const float jy = rng_next(sx, sy);
+    PrimaryRay r;
+    r.sx = (iteration + 1u) * x;
+    r.sy = (iteration + 2u) * y;
+    const float jx = rng_next(r.sx, r.sy);
+    const float jy = rng_next(r.sx, r.sy);
     float scx = (fx + jx) / cam.width_f;
     float scy = (fy + jy) / cam.height_f;
     scx = scx * 2.f - 1.f;
     scy = scy * 2.f - 1.f;
     const f3 p = (f.ref + f.H * scx) + f.V * scy;
-    const f3 d = normalizem(p - f.eye);
-    out.p0[i] = make_float4(f.eye.x, f.eye.y, f.eye.z, d.x);
-    out.p1[i] = make_float4(d.y, d.z, __uint_as_float(sx), __uint_as_float(sy));
-    if (sc.n_lights == 1u) out.lt[i] = light_distance(sc.lights[0], f.eye, d);
+    r.d = normalizem(p - f.eye);
+    return r;
 }
 
+// Readbacks: every pixel's ray at the slot the slot -> pixel mapping gives it, no path state (lane p2) stored.
 __global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, const BatchParams *__restrict__ bp, uint32_t it_stride,
                                                     uint32_t n_iterations, PathQueue out, uint32_t *counts_out,
                                                     uint32_t region_slots)
@@ -208,8 +202,13 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, const BatchPara
         const uint32_t pixel = pixel_of_slot(cam, j);
         uint32_t x;
         const uint32_t y = div_by(pixel, cam.width, cam.div_width, x);
-        for (uint32_t k = 0; k < n_iterations; ++k)
-            write_primary_ray(sc, cam, frame, x, y, it_first + k * it_stride, out, k * n_pixels + j);
+        for (uint32_t k = 0; k < n_iterations; ++k) {
+            const PrimaryRay r = primary_ray(cam, frame, x, y, it_first + k * it_stride);
+            const uint32_t i = k * n_pixels + j;
+            out.p0[i] = make_float4(frame.eye.x, frame.eye.y, frame.eye.z, r.d.x);
+            out.p1[i] = make_float4(r.d.y, r.d.z, __uint_as_float(r.sx), __uint_as_float(r.sy));
+            out.lt[i] = sc.n_lights == 1u ? light_distance(sc.lights[0], frame.eye, r.d) : __uint_as_float(kNoLightBits);
+        }
     }
     // rays per region of the new queue: full regions and a ragged last one
     const uint32_t n_regions = (total + region_slots - 1u) / region_slots;
@@ -224,6 +223,23 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, const BatchPara
 __device__ __forceinline__ uint32_t region_of(const Regions &rg, uint32_t k)
 {
     return static_cast<uint32_t>((static_cast<unsigned long long>(k) * rg.stride) % rg.n_regions);
+}
+// A wave takes the turns k0, k0 + n_waves, ... of its grid.  The 64-bit modulo above is a long routine; a wave
+// does it twice, when it starts, and from then on steps from one of its regions to the next with an add and
+// a conditional subtract: region(k + n_waves) = (region(k) + step) mod n_regions, step = (n_waves * stride)
+// mod n_regions.  The same (r, step) serve every phase of k_bounces: all phases walk the same regions.
+struct WaveTurns {
+    uint32_t r;     // region of the wave's next turn
+    uint32_t step;  // (n_waves * stride) mod n_regions
+};
+__device__ __forceinline__ WaveTurns wave_turns(const Regions &rg, uint32_t k0, uint32_t n_waves)
+{
+    return WaveTurns{region_of(rg, k0), region_of(rg, n_waves)};
+}
+__device__ __forceinline__ uint32_t next_region(const Regions &rg, uint32_t r, uint32_t step)
+{
+    r += step;  // both below n_regions < 2^31
+    return r >= rg.n_regions ? r - rg.n_regions : r;
 }
 
 // LDS by address.  The traversal kernel keeps LDS addresses (32-bit, as the ds_* instructions take them) in its
@@ -344,14 +360,16 @@ template <bool RENDER>
 __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg, PathQueue q,
                                                          float4 *__restrict__ hit_list, float4 *__restrict__ samples,
                                                          uint32_t last_segment,
-                                                         const BatchParams *__restrict__ bp, uint32_t primary)
+                                                         const BatchParams *__restrict__ bp)
 {
     const uint32_t sample_tag = RENDER ? bp->sample_tag : 0u;
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    for (uint32_t k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); k < rg.n_regions; k += n_waves) {
-      const uint32_t r = region_of(rg, k);
+    const uint32_t k0 = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const WaveTurns turns = wave_turns(rg, k0, n_waves);
+    uint32_t r = turns.r;
+    for (uint32_t k = k0; k < rg.n_regions; k += n_waves, r = next_region(rg, r, turns.step)) {
       const uint32_t n = rg.counts_in[r];
       const uint32_t region_base = r * rg.size;
       uint32_t hit_n0 = 0, hit_n1 = 0;
@@ -373,14 +391,14 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
             if (!RENDER) {
                 results[i] = make_float2(t, __int_as_float(code));
             } else if (code <= -2) {
-                const float4 c = primary ? primary_p2(bp->cam, i) : q.p2[i];
+                const float4 c = q.p2[i];
                 const float *rad = sc.lights[-(code + 2)].radiance;
                 const f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
                 // a non-finite sample is left to the accumulate kernel (which drops and counts it)
                 samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, __uint_as_float(sample_tag));
             } else {
                 append = code >= 0 && last_segment == 0u;
-                if (!append && !primary && (__float_as_uint(q.lt[i]) & kPoisonBit)) write_poisoned_sample(samples, q.p2[i], sample_tag);
+                if (!append && (__float_as_uint(q.lt[i]) & kPoisonBit)) write_poisoned_sample(samples, q.p2[i], sample_tag);
             }
         }
         if (RENDER)
@@ -447,8 +465,8 @@ template <int BLOCK, bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER, bool US
 __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &rg, const PathQueue &q, float4 *hit_list,
                                             float4 *samples, uint32_t last_segment, const TraversalCounters &tc, uint32_t n_nodes,
                                             uint32_t refill_at, uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
-                                            const BatchParams *bp, uint32_t primary, uint32_t lds_stack_entries,
-                                            int *stack_overflow, bool fill_lds)
+                                            const BatchParams *bp, uint32_t lds_stack_entries,
+                                            int *stack_overflow, bool fill_lds, WaveTurns turns)
 {
     const uint32_t sample_tag = RENDER ? bp->sample_tag : 0u;
     // lds_stride: 16-byte lanes between consecutive triangle records of the LDS copy of the scene.  4 = packed: the four
@@ -521,7 +539,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
     uint32_t prv_r = 0, prv_base = 0, prv_h0 = 0, prv_h1 = 0;                           // region before it
     bool cur_valid = false, prv_valid = false;
     bool cur_gen = false;  // parity of the current region; a lane whose gen differs works for the previous one
-    uint32_t nxt_r = k < rg.n_regions ? region_of(rg, k) : 0u;         // region of turn k and its ray count
+    uint32_t nxt_r = turns.r;                                          // region of turn k and its ray count
     uint32_t nxt_n = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
     {
         // per-lane ray state
@@ -573,7 +591,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                     cur_gen = !cur_gen;
                     k += n_waves;
                     // the count of the region after this one is fetched now, long before it is needed
-                    nxt_r = k < rg.n_regions ? region_of(rg, k) : 0u;
+                    nxt_r = next_region(rg, nxt_r, turns.step);
                     nxt_n = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
                 }
             }
@@ -610,7 +628,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                         offz = negz ? 16u : 0u;
                         // one-light scenes: the light's distance, known since the ray was made, is the limit
                         // the traversal starts with (a surface beyond the light cannot change the outcome)
-                        ltv = (USE_LT || (RENDER && !primary)) ? q.lt[slot] : __uint_as_float(kNoLightBits);
+                        ltv = (USE_LT || RENDER) ? q.lt[slot] : __uint_as_float(kNoLightBits);
                         h.t = (USE_LT && fabsf(ltv) >= 0.f) ? fabsf(ltv) : __builtin_inff();
                         h.id = -1;
                         node = kNodeAddresses ? static_cast<int>(lds_base) : 0;  // the root
@@ -737,7 +755,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                     results[slot] = make_float2(hit_t, __int_as_float(hit_code));
                 } else if (hit_code <= -2) {
                     // passCol = attenuation * intensity (frag:878-882, :901)
-                    const float4 c = primary ? primary_p2(bp->cam, slot) : q.p2[slot];
+                    const float4 c = q.p2[slot];
                     const float *rad = sc.lights[-(hit_code + 2)].radiance;
                     const f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
                     // a non-finite sample is left to the accumulate kernel (which drops and counts it)
@@ -782,31 +800,39 @@ __global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView
                                                         uint32_t last_segment,
                                                         TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
                                                         uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
-                                                        const BatchParams *__restrict__ bp, uint32_t primary,
+                                                        const BatchParams *__restrict__ bp,
                                                         uint32_t lds_stack_entries, int *__restrict__ stack_overflow)
 {
+    const WaveTurns turns = wave_turns(rg, blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), gridDim.x * (BLOCK / 64));
     extend_body<BLOCK, COUNT, EXACT, SCENE_LDS, RENDER, USE_LT>(sc, rg, q, hit_list, samples, last_segment, tc, n_nodes, refill_at,
-                                                                stack_entries, n_lds_nodes, lds_stride, bp, primary,
-                                                                lds_stack_entries, stack_overflow, true);
+                                                                stack_entries, n_lds_nodes, lds_stride, bp,
+                                                                lds_stack_entries, stack_overflow, true, turns);
 }
 
 // ----------------------------------------------------------------- shade
 
-// Arithmetic of the shading stage.  Division, square root, sine and cosine go through these helpers.  By
-// default they are the correctly rounded operations, which keep the stage within float noise of the CPU
-// restatement of the shader (4 of 32 891 random BSDF samples differ by more than 2e-3 relative).  Built with
-// -DPT_SHADE_FAST_MATH=1 they become the hardware's 1-ulp reciprocal and square root and its native sine /
-// cosine: 60 % fewer VALU instructions in the kernel, +2.5 % paths/s, and 99 such samples -- ill-conditioned
-// ones (grazing microfacet normals, refraction near total reflection) where an ulp is amplified.  The ray
-// generation, the intersection tests and the light test never use them.
+// Arithmetic of the shading stage.  Division, square root, sine and cosine go through these helpers.  The
+// shader's own sin / cos / pow / inversesqrt are whatever the GL driver makes of them (implementation-defined
+// precision in GLSL), so nothing past the first hit can be compared with the reference bit for bit; what the
+// reference's images can tell apart is decided on them (1920x1080 and 256x256 float images of seven
+// scene / depth cases, the 8-bit accumulation texture).  Measured on MI355X, per build:
+//   correctly rounded everything (PT_SHADE_FAST_MATH=0 PT_FAST_DIV=0 PT_FAST_SQRT=0): every reference image case
+//     green; against the CPU restatement of the shader 4 of 32 891 random BSDF samples differ by more than 2e-3;
+//   hardware reciprocal and square root (1 ulp), libm sine / cosine -- THE DEFAULT: every reference image case
+//     green (per-pixel relMSE against the reference at 1080p 7e-6, the noise floor being 0.61); 89 such samples --
+//     ill-conditioned ones (grazing microfacet normals, refraction near total reflection) where an ulp is
+//     amplified; 40 % fewer VALU instructions in the shading code, +1.5 % (Box) to +2 % (Veggie) paths/s;
+//   native sine / cosine as well (PT_FAST_SINCOS=1): 99 such samples, the same speed, and the 8-bit emulation then
+//     differs from the CPU restatement's by 3/255 in a texel where 2/255 is the bound: not taken.
+// The ray generation, the intersection tests and the light test never use these helpers.
 #ifndef PT_SHADE_FAST_MATH
 #define PT_SHADE_FAST_MATH 0
 #endif
 #ifndef PT_FAST_DIV
-#define PT_FAST_DIV PT_SHADE_FAST_MATH
+#define PT_FAST_DIV 1
 #endif
 #ifndef PT_FAST_SQRT
-#define PT_FAST_SQRT PT_SHADE_FAST_MATH
+#define PT_FAST_SQRT 1
 #endif
 #ifndef PT_FAST_SINCOS
 #define PT_FAST_SINCOS PT_SHADE_FAST_MATH
@@ -1148,7 +1174,8 @@ __device__ __forceinline__ f3 interpolated_normal(float4 s0, float4 s1, float4 s
     const f3 e0 = v1 - v0, e1 = v2 - v0, eP = p - v0;
     const float e00 = dotm(e0, e0), e01 = dotm(e0, e1), e11 = dotm(e1, e1);
     const float e0P = dotm(e0, eP), e1P = dotm(e1, eP);
-    const float inv = sdiv(1.f, e00 * e11 - e01 * e01);
+    // (a correctly rounded division, not sdiv: the primary hits' normals are compared with the reference's bit for bit)
+    const float inv = 1.f / (e00 * e11 - e01 * e01);
     const float bv = (e11 * e0P - e01 * e1P) * inv;
     const float bw = (e00 * e1P - e01 * e0P) * inv;
     const float bu = 1.f - bv - bw;
@@ -1166,14 +1193,14 @@ __device__ __forceinline__ f3 interpolated_normal(float4 s0, float4 s1, float4 s
 // (A device function for the same reason as extend_body; BLOCK = threads per block of the launch it runs in.)
 template <int BLOCK>
 __device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &rg, const PathQueue &in, const float4 *hit_list,
-                                           const PathQueue &out, float4 *samples, const BatchParams *bp, uint32_t primary,
-                                           uint32_t final_bounce)
+                                           const PathQueue &out, float4 *samples, const BatchParams *bp,
+                                           uint32_t final_bounce, WaveTurns turns)
 {
     const uint32_t sample_tag = bp->sample_tag;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     uint32_t k = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    uint32_t nxt_r = k < rg.n_regions ? region_of(rg, k) : 0u;
+    uint32_t nxt_r = turns.r;
     uint32_t nxt_packed = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
     while (k < rg.n_regions) {
       const uint32_t r = nxt_r;
@@ -1183,7 +1210,7 @@ __device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &r
       const uint32_t packed = nxt_packed;
       k += n_waves;
       if (k < rg.n_regions) {  // the next region's count is fetched while this one is shaded
-          nxt_r = region_of(rg, k);
+          nxt_r = next_region(rg, nxt_r, turns.step);
           nxt_packed = rg.counts_in[nxt_r];
       }
       const uint32_t n0 = packed & 0xFFFFu, n1 = packed >> 16;
@@ -1220,7 +1247,7 @@ __device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &r
         if (take0 || take1) {
             const float4 rec = hit_list[region_base + (take1 ? last_slot - j : j)];
             const uint32_t i = region_base + __float_as_uint(rec.z);
-            const float4 a = in.p0[i], b = in.p1[i], c = primary ? primary_p2(bp->cam, i) : in.p2[i];
+            const float4 a = in.p0[i], b = in.p1[i], c = in.p2[i];
             const int code = __float_as_int(rec.y);
             const f3 thr = mk(c.x, c.y, c.z);
             {
@@ -1299,9 +1326,10 @@ __device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &r
 __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, Regions rg, PathQueue in,
                                                    const float4 *__restrict__ hit_list, PathQueue out,
                                                    float4 *__restrict__ samples, const BatchParams *__restrict__ bp,
-                                                   uint32_t primary, uint32_t final_bounce)
+                                                   uint32_t final_bounce)
 {
-    shade_body<kBlock>(sc, rg, in, hit_list, out, samples, bp, primary, final_bounce);
+    const WaveTurns turns = wave_turns(rg, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), gridDim.x * (kBlock / 64));
+    shade_body<kBlock>(sc, rg, in, hit_list, out, samples, bp, final_bounce, turns);
 }
 
 // ------------------------------------------------- all bounces in one launch
@@ -1321,9 +1349,25 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
 // The primary rays are region-local as well: slot i of the queue is sample i / (W * H) of the pixel that slot
 // i mod (W * H) maps to, so the wave that will trace a region also makes its rays (what k_raygen does for the
 // whole queue at once), and reads them back from the cache rather than from memory.
+// The primary rays of the render loop, region by region: slot i of the batch is sample i / (W * H) of the pixel
+// that slot i mod (W * H) maps to, so a region's rays are a function of its slot numbers, and the wave that will
+// trace a region can also make its rays (and read them back from the cache rather than from memory).
+//
+// cull: a ray that meets neither the scene's bounds nor a light can only end as a miss, which adds nothing
+// (frag:876: escape = black).  The host projects the scene's bounding box and the lights' rectangles onto the
+// image and hands over the window of pixels outside of which every ray is of that kind (DeviceCamera::cull_*;
+// more than half of all pixels with the reference's camera, which sees the box in the middle of a wide frame).
+// Rays of pixels outside the window are counted and never made -- the 64 slots a wave handles together are an
+// 8 x 8 tile of the image, so mostly a whole wave skips the work --, the others are packed to the front of the
+// region (ballot + prefix rank, as everywhere).  Because a ray's position in the region then no longer says
+// which pixel it belongs to, lane p2 (throughput 1, the path's sample slot iteration_in_batch * W*H + pixel) is
+// stored for primary rays like for all others.  cull = 0 when the reference's non-finite samples are wanted one
+// for one (a ray exactly parallel to a triangle's plane is a hit at t = inf there wherever it points).
+// culled_out[r]: rays of region r not made.
 template <int BLOCK>
 __device__ __forceinline__ void raygen_regions(const SceneView &sc, const BatchParams *bp, uint32_t it_stride, uint32_t n_iterations,
-                                               const PathQueue &out, const Regions &rg)
+                                               const PathQueue &out, const Regions &rg, uint32_t *culled_out, uint32_t cull,
+                                               WaveTurns turns)
 {
     const DeviceCamera cam = bp->cam;
     const uint32_t it_first = bp->it_first;
@@ -1332,18 +1376,56 @@ __device__ __forceinline__ void raygen_regions(const SceneView &sc, const BatchP
     const PrimaryFrame frame = primary_frame(cam);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-    for (uint32_t k = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); k < rg.n_regions; k += n_waves) {
-        const uint32_t r = region_of(rg, k);
+    uint32_t r = turns.r;
+    for (uint32_t k = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); k < rg.n_regions; k += n_waves, r = next_region(rg, r, turns.step)) {
         const uint32_t base = r * rg.size, n = min(rg.size, total - base);
-        for (uint32_t i = base + lane; i < base + n; i += 64u) {
-            uint32_t j;
-            const uint32_t it = div_by(i, n_pixels, cam.div_pixels, j);
-            uint32_t x;
-            const uint32_t y = div_by(pixel_of_slot(cam, j), cam.width, cam.div_width, x);
-            write_primary_ray(sc, cam, frame, x, y, it_first + it * it_stride, out, i);
+        uint32_t out_n = 0;  // wave-uniform: rays written to this region so far
+        for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+            bool keep = false;
+            uint32_t x = 0, y = 0, it = 0, pixel = 0;
+            if (i0 + lane < n) {
+                uint32_t j;
+                it = div_by(base + i0 + lane, n_pixels, cam.div_pixels, j);
+                pixel = pixel_of_slot(cam, j);
+                y = div_by(pixel, cam.width, cam.div_width, x);
+                keep = !cull || (x >= cam.cull_x0 && x <= cam.cull_x1 && y >= cam.cull_y0 && y <= cam.cull_y1);
+            }
+            const unsigned long long kept = __ballot(keep);
+            if (kept == 0ull) continue;  // (wave-uniform) nothing of this tile can meet anything
+            float4 o0, o1, o2;
+            float lt = __uint_as_float(kNoLightBits);
+            if (keep) {
+                const PrimaryRay pr = primary_ray(cam, frame, x, y, it_first + it * it_stride);
+                if (sc.n_lights == 1u) lt = light_distance(sc.lights[0], frame.eye, pr.d);
+                o0 = make_float4(frame.eye.x, frame.eye.y, frame.eye.z, pr.d.x);
+                o1 = make_float4(pr.d.y, pr.d.z, __uint_as_float(pr.sx), __uint_as_float(pr.sy));
+                o2 = make_float4(1.f, 1.f, 1.f, __uint_as_float(it * n_pixels + pixel));
+            }
+            if (keep) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(kept >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(kept), 0u));
+                const uint32_t dst = base + out_n + rank;
+                out.p0[dst] = o0;
+                out.p1[dst] = o1;
+                out.p2[dst] = o2;
+                out.lt[dst] = lt;
+            }
+            out_n += static_cast<uint32_t>(__popcll(kept));
         }
-        if (lane == 0) rg.counts_out[r] = n;
+        if (lane == 0) {
+            rg.counts_out[r] = out_n;
+            culled_out[r] = n - out_n;
+        }
     }
+}
+
+// The same as a kernel of its own, for batches that run as one launch per kernel and bounce.
+__global__ void __launch_bounds__(kBlock) k_raygen_regions(SceneView sc, const BatchParams *__restrict__ bp, uint32_t it_stride,
+                                                            uint32_t n_iterations, PathQueue out, Regions rg, uint32_t *culled_out,
+                                                            uint32_t cull)
+{
+    const WaveTurns turns = wave_turns(rg, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), gridDim.x * (kBlock / 64));
+    raygen_regions<kBlock>(sc, bp, it_stride, n_iterations, out, rg, culled_out, cull, turns);
 }
 
 template <int BLOCK, int SCENE_LDS, bool USE_LT>
@@ -1353,9 +1435,12 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 256 ? 5 : 4) k_bounces(SceneVi
                                                       int *stack_overflow, uint32_t it_stride, uint32_t n_iterations)
 {
     const TraversalCounters no_counters{nullptr, nullptr, nullptr};
+    // the wave's regions are the same in every phase: where it starts and how it steps is worked out once
+    WaveTurns turns;
     {
         const Regions rg{nullptr, L.counts, L.n_regions, L.stride, L.size};
-        raygen_regions<BLOCK>(sc, bp, it_stride, n_iterations, L.q[0], rg);
+        turns = wave_turns(rg, blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), gridDim.x * (BLOCK / 64));
+        raygen_regions<BLOCK>(sc, bp, it_stride, n_iterations, L.q[0], rg, L.counts + static_cast<size_t>(2u * L.depth + 1u) * L.pitch, 1u, turns);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
     for (uint32_t b = 0; b < L.depth; ++b) {
@@ -1363,12 +1448,12 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 256 ? 5 : 4) k_bounces(SceneVi
         uint32_t *rays = L.counts + static_cast<size_t>(b) * L.pitch, *hits = L.counts + static_cast<size_t>(L.depth + 1u + b) * L.pitch;
         const Regions re{rays, hits, L.n_regions, L.stride, L.size};
         extend_body<BLOCK, false, false, SCENE_LDS, true, USE_LT>(sc, re, L.q[b & 1u], L.hit_list, L.samples, last, no_counters, n_nodes,
-                                                                 refill_at, stack_entries, n_lds_nodes, lds_stride, bp, b == 0u ? 1u : 0u,
-                                                                 lds_stack_entries, stack_overflow, b == 0u);
+                                                                 refill_at, stack_entries, n_lds_nodes, lds_stride, bp,
+                                                                 lds_stack_entries, stack_overflow, b == 0u, turns);
         if (last) break;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         const Regions rs{hits, L.counts + static_cast<size_t>(b + 1u) * L.pitch, L.n_regions, L.stride, L.size};
-        shade_body<BLOCK>(sc, rs, L.q[b & 1u], L.hit_list, L.q[(b + 1u) & 1u], L.samples, bp, b == 0u ? 1u : 0u, 0u);
+        shade_body<BLOCK>(sc, rs, L.q[b & 1u], L.hit_list, L.q[(b + 1u) & 1u], L.samples, bp, 0u, turns);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 }
@@ -1392,6 +1477,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
                                                         unsigned long long *__restrict__ segments_total,
                                                         unsigned long long *__restrict__ shade_totals,
                                                         unsigned long long *__restrict__ nan_counter,
+                                                        unsigned long long *__restrict__ culled_total,
                                                         uint8_t *__restrict__ rgba8, const BatchParams *__restrict__ bp,
                                                         uint32_t it_stride)
 {
@@ -1416,12 +1502,21 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
         }
     }
     {
-        // segments of this batch = sum of all live counts of all bounces
-        unsigned long long s = 0;
+        // segments of this batch = sum of all live counts of all bounces, plus the primary rays that ray
+        // generation found to miss the scene and did not enqueue (row 2 * n_rows + 1): a path's first segment
+        // all the same
+        unsigned long long s = 0, culled = 0;
         for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_rows * n_regions; k += gridDim.x * kBlock)
             s += counts[(k / n_regions) * pitch + (k % n_regions)];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n_regions; k += gridDim.x * kBlock)
+            culled += counts[static_cast<size_t>(2u * n_rows + 1u) * pitch + k];
+        s += culled;
+        for (int off = 32; off > 0; off >>= 1) {
+            s += __shfl_down(s, off);
+            culled += __shfl_down(culled, off);
+        }
         if ((threadIdx.x & 63u) == 0 && s != 0) atomicAdd(segments_total, s);
+        if ((threadIdx.x & 63u) == 0 && culled != 0) atomicAdd(culled_total, culled);
     }
     unsigned long long dropped = 0;
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pixels; p += gridDim.x * kBlock) {
@@ -1650,6 +1745,13 @@ void launch_raygen(hipStream_t s, LaunchShape g, const SceneView &scene, const B
                        counts_out, region_size);
 }
 
+void launch_raygen_regions(hipStream_t s, LaunchShape g, const SceneView &scene, const BatchParams *params, uint32_t it_stride,
+                           uint32_t n_iterations, PathQueue out, Regions regions, uint32_t *culled_out, bool cull)
+{
+    hipLaunchKernelGGL(k_raygen_regions, dim3(resident_grid(k_raygen_regions, 0, g)), dim3(kBlock), 0, s, scene, params, it_stride,
+                       n_iterations, out, regions, culled_out, cull ? 1u : 0u);
+}
+
 namespace {
 // Dynamic LDS of the traversal kernel: as much of the scene as the block may hold, then the per-lane stacks.
 // Four blocks of 256 threads per CU with 40 KB each, or one block of 1024 threads with 160 KB (16 waves per CU
@@ -1740,7 +1842,7 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
 
 // The instantiation of the traversal kernel for a plan and a set of switches, as a generic function pointer.
 using ExtendKernel = void (*)(SceneView, Regions, PathQueue, float4 *, float4 *, uint32_t, TraversalCounters, uint32_t, uint32_t,
-                              uint32_t, uint32_t, uint32_t, const BatchParams *, uint32_t, uint32_t, int *);
+                              uint32_t, uint32_t, uint32_t, const BatchParams *, uint32_t, int *);
 template <int BLOCK, int L>
 ExtendKernel extend_kernel_for(bool counting, bool exact, bool render, bool use_lt)
 {
@@ -1803,16 +1905,15 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
         return v < 0 ? 0 : (v > 64 ? 64 : v);
     }();
     const bool render = out.render;
-    const uint32_t primary = out.primary ? 1u : 0u;
     const bool exact_parallel = out.exact_parallel;
     const uint32_t last = out.last_segment ? 1u : 0u;
     if (!use_bvh) {
         if (render)
             hipLaunchKernelGGL(k_extend_scan<true>, dim3(resident_grid(k_extend_scan<true>, 0, g)), dim3(kBlock), 0, s, scene,
-                               regions, q, out.hit_list, out.samples, last, out.params, primary);
+                               regions, q, out.hit_list, out.samples, last, out.params);
         else
             hipLaunchKernelGGL(k_extend_scan<false>, dim3(resident_grid(k_extend_scan<false>, 0, g)), dim3(kBlock), 0, s, scene,
-                               regions, q, out.hit_list, out.samples, last, out.params, primary);
+                               regions, q, out.hit_list, out.samples, last, out.params);
         return;
     }
     const bool counting = tc.nodes_visited != nullptr;
@@ -1824,7 +1925,7 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     const ExtendKernel kernel = extend_kernel(plan, counting, exact_parallel, render, use_lt);
     hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block, "PT_EXT_PER_CU")), dim3(plan.block), plan.bytes, s,
                        scene, regions, q, out.hit_list, out.samples, last, tc, n_nodes, refill_at, stack_entries, plan.n_lds_nodes,
-                       plan.stride, out.params, primary, plan.lds_stack_entries, out.stack_overflow);
+                       plan.stride, out.params, plan.lds_stack_entries, out.stack_overflow);
 }
 
 namespace {
@@ -1878,20 +1979,21 @@ void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32
 }
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
-                  const float4 *hit_list, PathQueue out, float4 *samples, const BatchParams *params, bool primary,
+                  const float4 *hit_list, PathQueue out, float4 *samples, const BatchParams *params,
                   bool final_bounce)
 {
     hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g, kBlock, "PT_SHADE_PER_CU")), dim3(kBlock), 0, s, scene, regions, in, hit_list, out,
-                       samples, params, primary ? 1u : 0u, final_bounce ? 1u : 0u);
+                       samples, params, final_bounce ? 1u : 0u);
 }
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
                        uint32_t pitch, unsigned long long *segments_total, unsigned long long *shade_totals,
-                       unsigned long long *nan_counter, uint8_t *rgba8, const BatchParams *params, uint32_t it_stride)
+                       unsigned long long *nan_counter, unsigned long long *culled_total, uint8_t *rgba8, const BatchParams *params,
+                       uint32_t it_stride)
 {
     hipLaunchKernelGGL(k_accumulate, dim3(g.blocks), dim3(kBlock), 0, s, samples, sum, n_pixels, n_iterations, counts,
-                       n_rows, n_regions, pitch, segments_total, shade_totals, nan_counter,
+                       n_rows, n_regions, pitch, segments_total, shade_totals, nan_counter, culled_total,
                        rgba8, params, it_stride);
 }
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -131,6 +132,8 @@ struct pt_camera {
     explicit pt_camera(const pt::Camera &c) : cam(c) {}
 };
 
+constexpr size_t kCounters = 16;  // device counters behind pt_stats (pt_renderer::d_counters)
+
 struct pt_renderer {
     pt_config cfg{};
     int device = 0;
@@ -184,7 +187,7 @@ struct pt_renderer {
     uint32_t next_lane = 0;
     uint32_t lanes_in_use = 1;                    // 2 unless the second set did not fit in memory
     bool scene_in_lds = true;                 // extend keeps nodes (and triangles) in LDS when they fit
-    unsigned long long *d_counters = nullptr; // [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics [12] hits shaded [13] shade batches
+    unsigned long long *d_counters = nullptr; // kCounters words: [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics [12] hits shaded [13] shade batches [14] primary rays culled at generation [15] spare
 
     // pt_read_hit_ids / pt_trace_rays report hits at t = +inf on exactly
     // parallel triangles like the reference does (see k_extend_bvh).
@@ -206,6 +209,10 @@ struct pt_renderer {
 
     // per-batch scalars on the device, one block per set of batch buffers (kernels.h, BatchParams)
     pt::BatchParams *d_params = nullptr;
+
+    // World-space points whose projections bound everything a primary ray can meet: the corners of the mesh's
+    // bounding box and of every light's rectangle (update_cull_window).
+    std::vector<std::array<double, 3>> cull_points;
 
     // the deep ends of the traversal kernel's stacks for a tree that is read from memory (kernels.h,
     // ExtendOutput::stack_overflow): one buffer per stream, null when the stacks fit in LDS
@@ -349,8 +356,9 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         r->region_size = r->region_size_env ? r->region_size_env : static_cast<uint32_t>(size);
     }
     r->region_pitch = static_cast<uint32_t>((r->capacity + r->region_size - 1) / r->region_size);
-    // rows 0..depth: live rays per region and bounce; rows depth+1..2*depth: surface hits per region and bounce
-    PT_HIP(hipMalloc(&r->d_counts, static_cast<size_t>(2 * r->cfg.max_depth + 1) * r->region_pitch * sizeof(uint32_t)));
+    // rows 0..depth: live rays per region and bounce; rows depth+1..2*depth: surface hits per region and bounce;
+    // row 2*depth+1: primary rays per region that ray generation did not enqueue
+    PT_HIP(hipMalloc(&r->d_counts, static_cast<size_t>(2 * r->cfg.max_depth + 2) * r->region_pitch * sizeof(uint32_t)));
     // whole regions: the hit list of a region is filled from both of its ends
     PT_HIP(hipMalloc(&r->d_hits, static_cast<size_t>(r->region_pitch) * r->region_size * sizeof(float4)));
     PT_HIP(hipMalloc(&r->d_samples, r->capacity * sizeof(float4)));
@@ -367,7 +375,7 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
                 if (e == hipSuccess) e = hipMalloc(&r->q2[b].lt, r->capacity * sizeof(float));
             }
             if (e == hipSuccess)
-                e = hipMalloc(&r->d_counts2, static_cast<size_t>(2 * r->cfg.max_depth + 1) * r->region_pitch * sizeof(uint32_t));
+                e = hipMalloc(&r->d_counts2, static_cast<size_t>(2 * r->cfg.max_depth + 2) * r->region_pitch * sizeof(uint32_t));
             if (e == hipSuccess) e = hipMalloc(&r->d_hits2, static_cast<size_t>(r->region_pitch) * r->region_size * sizeof(float4));
             if (e == hipSuccess) e = hipMalloc(&r->d_samples2, r->capacity * sizeof(float4));
             if (e == hipSuccess) e = hipMemsetAsync(r->d_samples2, 0, r->capacity * sizeof(float4), r->stream2);
@@ -495,11 +503,90 @@ pt::LaunchShape shape_for(const pt_renderer *r, size_t work_items)
                            static_cast<uint32_t>(std::max<size_t>(1, regions))};
 }
 
+// The window of pixels outside of which no primary ray can meet the scene's bounds or a light
+// (DeviceCamera::cull_*; kernels.hip, raygen_regions).  A pixel's rays go through image-plane points
+// forward + H * sx + V * sy with H = right * tan * aspect, V = up * tan and (sx, sy) inside the pixel's square
+// (frag:306-320); a world point P is seen at the (sx, sy) that solves forward + H sx + V sy = lambda (P - eye),
+// lambda > 0.  All points in front of the eye: the convex hull of their images holds the image of everything
+// between them, and its bounding rectangle -- widened by a pixel and by what the traversal's padded slabs let
+// through -- is the window.  Any point beside or behind the eye, or a frame that cannot be inverted: the whole image.
+void update_cull_window(pt_renderer *r)
+{
+    pt::DeviceCamera &c = r->cam;
+    c.cull_x0 = c.cull_y0 = 0;
+    c.cull_x1 = r->width ? r->width - 1 : 0;
+    c.cull_y1 = r->height ? r->height - 1 : 0;
+    if (r->cull_points.empty() || r->width == 0 || r->height == 0) return;
+    const double tan_h = c.tan_half_fov, aspect = c.aspect;
+    double H[3], V[3], F[3], E[3];
+    for (int k = 0; k < 3; ++k) {
+        H[k] = double(c.right[k]) * tan_h * aspect;
+        V[k] = double(c.up[k]) * tan_h;
+        F[k] = c.forward[k];
+        E[k] = c.eye[k];
+    }
+    auto det3 = [](const double a[3], const double b[3], const double d[3]) {
+        return a[0] * (b[1] * d[2] - b[2] * d[1]) - b[0] * (a[1] * d[2] - a[2] * d[1]) + d[0] * (a[1] * b[2] - a[2] * b[1]);
+    };
+    double sx_lo = 1e300, sx_hi = -1e300, sy_lo = 1e300, sy_hi = -1e300, lambda_max = 0.0;
+    bool any_in_front = false, any_behind = false;
+    for (const std::array<double, 3> &P : r->cull_points) {
+        // [H V -v] (sx, sy, lambda)^T = -F
+        const double nv[3] = {-(P[0] - E[0]), -(P[1] - E[1]), -(P[2] - E[2])}, nF[3] = {-F[0], -F[1], -F[2]};
+        const double det = det3(H, V, nv);
+        if (!(std::fabs(det) > 1e-30) || !std::isfinite(det)) return;
+        const double sx = det3(nF, V, nv) / det, sy = det3(H, nF, nv) / det, lambda = det3(H, V, nF) / det;
+        if (!std::isfinite(lambda) || !std::isfinite(sx) || !std::isfinite(sy)) return;
+        // lambda <= 0: the point lies in or behind the plane through the eye parallel to the image plane, where
+        // no primary ray goes (every ray direction forward + H sx + V sy has the same positive component across it)
+        if (!(lambda > 1e-9)) {
+            any_behind = true;
+            continue;
+        }
+        any_in_front = true;
+        sx_lo = std::min(sx_lo, sx), sx_hi = std::max(sx_hi, sx);
+        sy_lo = std::min(sy_lo, sy), sy_hi = std::max(sy_hi, sy);
+        lambda_max = std::max(lambda_max, lambda);
+    }
+    auto empty_window = [&]() { c.cull_x0 = 1, c.cull_x1 = 0, c.cull_y0 = 1, c.cull_y1 = 0; };
+    if (!any_in_front) {
+        // everything lies behind that plane, and so does all that is between the points: nothing is in view.
+        // (Points within the padding of the plane count as in front: lambda > 1e-9 is a test with a wide margin,
+        // since 1 / lambda is the point's distance in units of |forward|.)
+        empty_window();
+        return;
+    }
+    if (any_behind) return;  // the bounds straddle the plane: their image is unbounded, the whole frame stays
+    // The traversal widens every slab by 2^-17 * max(|origin|, scene radius) (kernels.hip, extend_body): a ray may
+    // pass that far outside the box and still be tested against what is inside.  Seen from the eye at the nearest
+    // point's distance 1 / lambda_max that is an offset of pad * lambda_max on the image plane at distance 1, i.e.
+    // pad * lambda_max / tan in units of (sx, sy); taken sixteen times over, plus one whole pixel.
+    double reach = r->view.scene_radius;
+    for (int k = 0; k < 3; ++k) reach = std::max(reach, std::fabs(E[k]));
+    const double pad_s = 16.0 * (reach * 7.62939453125e-6) * lambda_max / std::max(1e-12, tan_h * std::min(1.0, aspect));
+    const double W = r->width, Hh = r->height;
+    // pixel column x covers fragcoord + jitter in [x + 0.5, x + 1.5] (jitter in [0, 1], frag:310), sx = 2 (fragcoord + jitter) / W - 1
+    const double fx_lo = (sx_lo - pad_s + 1.0) * 0.5 * W - 1.0, fx_hi = (sx_hi + pad_s + 1.0) * 0.5 * W + 1.0;
+    const double fy_lo = (sy_lo - pad_s + 1.0) * 0.5 * Hh - 1.0, fy_hi = (sy_hi + pad_s + 1.0) * 0.5 * Hh + 1.0;
+    auto lower = [](double f, double n) { return static_cast<uint32_t>(std::min(n, std::max(0.0, std::floor(f - 1.5)))); };  // at or before the first x with x + 1.5 >= f
+    auto upper = [](double f, double n) { return std::min(n - 1.0, std::ceil(f - 0.5)); };                                 // at or after the last x with x + 0.5 <= f
+    const double ux = upper(fx_hi, W), uy = upper(fy_hi, Hh);
+    c.cull_x0 = lower(fx_lo, W);
+    c.cull_y0 = lower(fy_lo, Hh);
+    if (ux < 0.0 || uy < 0.0 || c.cull_x0 >= r->width || c.cull_y0 >= r->height) {
+        empty_window();  // everything lies outside the frame
+        return;
+    }
+    c.cull_x1 = static_cast<uint32_t>(ux);
+    c.cull_y1 = static_cast<uint32_t>(uy);
+}
+
 int reset_accumulation(pt_renderer *r)
 {
+    update_cull_window(r);  // every change of camera, size or scene lights comes through here
     if (r->stream2) PT_HIP(hipStreamSynchronize(r->stream2));  // its last accumulate still adds to the sum
     PT_HIP(hipMemsetAsync(r->d_sum, 0, static_cast<size_t>(r->width) * r->height * sizeof(float4), r->stream));
-    PT_HIP(hipMemsetAsync(r->d_counters, 0, 14 * sizeof(unsigned long long), r->stream));
+    PT_HIP(hipMemsetAsync(r->d_counters, 0, kCounters * sizeof(unsigned long long), r->stream));
     if (r->d_rgba8) PT_HIP(hipMemsetAsync(r->d_rgba8, 0, static_cast<size_t>(r->width) * r->height * 4, r->stream));
     mark_main_stream_work(r);
     r->local_iterations = 0;
@@ -572,8 +659,10 @@ void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
         return;
     }
     {
+        // (with the exact-samples pass a ray that misses the scene may still be a hit at t = inf: nothing is culled)
         Timed t(r, 0, st);
-        pt::launch_raygen(st, g, r->view, bp, r->world, kb, q[0], d_counts, region_size_for(r, n_paths));
+        pt::launch_raygen_regions(st, g, r->view, bp, r->world, kb, q[0], regions_for(r, n_paths, 0, 0, d_counts),
+                                  d_counts + static_cast<size_t>(2 * depth + 1) * r->region_pitch, !exact_samples && r->cfg.use_bvh != 0);
     }
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = q[b & 1], &out = q[(b + 1) & 1];
@@ -585,7 +674,7 @@ void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
         const int hit_row = static_cast<int>(depth + 1 + b);
         {
             Timed t(r, 1, st);
-            pt::ExtendOutput eo{true, d_hits, d_samples, true, last, exact_samples, bp, b == 0, r->d_stack_overflow[lane]};
+            pt::ExtendOutput eo{true, d_hits, d_samples, true, last, exact_samples, bp, r->d_stack_overflow[lane]};
             pt::launch_extend(st, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n_paths, b, hit_row, d_counts), in,
                               eo, tc, r->n_nodes, r->scene_in_lds);
         }
@@ -593,7 +682,7 @@ void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
             Timed t(r, 2, st);
             pt::launch_shade(st, g, r->view,
                              regions_for(r, n_paths, static_cast<uint32_t>(hit_row), static_cast<int>(b) + 1, d_counts), in, d_hits,
-                             out, d_samples, bp, b == 0, final_shade);
+                             out, d_samples, bp, final_shade);
         }
     }
 }
@@ -628,7 +717,7 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
             Timed t(r, 3, st);
             pt::launch_accumulate(st, shape_for(r, n_pixels), d_samples, r->d_sum, static_cast<uint32_t>(n_pixels), kb, d_counts,
                                   depth, regions_for(r, n_paths, 0, -1, d_counts).n_regions, r->region_pitch, r->d_counters,
-                                  r->d_counters + 12, r->d_counters + 1, r->d_rgba8, r->d_params + lane, r->world);
+                                  r->d_counters + 12, r->d_counters + 1, r->d_counters + 14, r->d_rgba8, r->d_params + lane, r->world);
         }
         if (r->two_lanes) {
             PT_HIP(hipEventRecord(r->ev_accum[lane], st));
@@ -864,6 +953,20 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
     float radius = 0.f;
     for (int a = 0; a < 3; ++a) radius = std::max(radius, std::max(std::fabs(bounds_lo[a]), std::fabs(bounds_hi[a])));
     r->view.scene_radius = radius;
+    r->cull_points.clear();
+    for (int c = 0; c < 8; ++c)
+        r->cull_points.push_back({double((c & 1) ? bounds_hi[0] : bounds_lo[0]), double((c & 2) ? bounds_hi[1] : bounds_lo[1]),
+                                  double((c & 4) ? bounds_hi[2] : bounds_lo[2])});
+    for (uint32_t l = 0; l < sc->n_lights; ++l) {
+        // the light is the unit square |x|, |y| <= 0.5 of its own z = 0 plane (frag:363-382); column-major transform
+        const float *m = sc->lights + 20 * static_cast<size_t>(l) + 4;
+        for (int c = 0; c < 4; ++c) {
+            const double lx = (c & 1) ? 0.5 : -0.5, ly = (c & 2) ? 0.5 : -0.5;
+            const double w = m[3] * lx + m[7] * ly + m[15];
+            r->cull_points.push_back({(m[0] * lx + m[4] * ly + m[12]) / w, (m[1] * lx + m[5] * ly + m[13]) / w,
+                                      (m[2] * lx + m[6] * ly + m[14]) / w});
+        }
+    }
     return PT_OK;
 }
 
@@ -1144,7 +1247,7 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
         if (!ok) return bail(fail(PT_ERR_DEVICE, "hipStreamCreate / hipEventCreate failed"));
     }
     if ((rc = upload_scene(r, scene)) != PT_OK) return bail(rc);
-    if (hipMalloc(&r->d_counters, 14 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc(&r->d_counters, kCounters * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc(&r->d_params, 2 * sizeof(pt::BatchParams)) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipMalloc failed"));
     if (cfg.profile & 8u) r->view.deep_stack_lds_entries = 4;  // tests: make deep stacks overflow early
@@ -1272,14 +1375,15 @@ int pt_render(pt_renderer *r, uint32_t n_iterations)
 
 namespace {
 struct StateHeader {
-    char magic[8];  // "PTAMDST2"
+    char magic[8];  // "PTAMDST3" ("PTAMDST2": the same header with 14 counters)
     uint32_t width, height, max_depth, rank, world, reserved;
     uint64_t local_iterations, paths, scene_hash;
     float fov_y_degrees;
     float eye[3], forward[3], up[3], right[3];
-    uint64_t counters[14];  // the device counters behind pt_stats (segments, non-finite samples, ...), so that
-                            // the statistics of a resumed render cover the whole render like `paths` does
+    uint64_t counters[kCounters];  // the device counters behind pt_stats (segments, non-finite samples, ...), so that
+                                   // the statistics of a resumed render cover the whole render like `paths` does
 };
+constexpr size_t kStateHeaderV2Bytes = sizeof(StateHeader) - 2 * sizeof(uint64_t);  // version 2 ends after counters[13]
 }  // namespace
 
 int pt_save_state(pt_renderer *r, const char *path)
@@ -1294,7 +1398,7 @@ int pt_save_state(pt_renderer *r, const char *path)
     if (rc != PT_OK) return rc;
     StateHeader h;
     std::memset(&h, 0, sizeof(h));
-    std::memcpy(h.magic, "PTAMDST2", 8);
+    std::memcpy(h.magic, "PTAMDST3", 8);
     h.width = r->width;
     h.height = r->height;
     h.max_depth = r->cfg.max_depth;
@@ -1334,7 +1438,8 @@ int pt_load_state(pt_renderer *r, const char *path)
     StateHeader h;
     const size_t n = static_cast<size_t>(r->width) * r->height * 4;
     std::vector<float> sum(n);
-    bool ok = std::fread(&h, sizeof(h), 1, f) == 1;
+    std::memset(&h, 0, sizeof(h));
+    bool ok = std::fread(&h, kStateHeaderV2Bytes, 1, f) == 1;
     if (ok && std::memcmp(h.magic, "PTAMDST1", 8) == 0) {
         // Files of the first format carry no counters and a scene hash computed byte by byte, which this build
         // cannot check against its own (word-wise) hash: refused by name rather than as a damaged file.
@@ -1342,7 +1447,12 @@ int pt_load_state(pt_renderer *r, const char *path)
         return fail(PT_ERR_STATE, std::string("pt_load_state: ") + path +
                                       " is a version-1 state file (PTAMDST1); this build reads version 2 only -- render again and save");
     }
-    ok = ok && std::memcmp(h.magic, "PTAMDST2", 8) == 0;
+    // version 3 carries two more counters (primary rays culled at generation, one spare); a version-2 file has
+    // none of the former, and its render had none either
+    if (ok && std::memcmp(h.magic, "PTAMDST3", 8) == 0)
+        ok = std::fread(reinterpret_cast<char *>(&h) + kStateHeaderV2Bytes, sizeof(h) - kStateHeaderV2Bytes, 1, f) == 1;
+    else
+        ok = ok && std::memcmp(h.magic, "PTAMDST2", 8) == 0;
     const bool fits = ok && h.width == r->width && h.height == r->height;
     ok = fits && std::fread(sum.data(), sizeof(float), n, f) == n && std::fgetc(f) == EOF;
     std::fclose(f);
@@ -1488,7 +1598,7 @@ int read_primary(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, flo
     pt::launch_set_batch(r->stream, r->d_params, r->cam, iteration, 0u);
     pt::launch_raygen(r->stream, g, r->view, r->d_params, 1, 1, r->q[0], r->d_counts, region_size_for(r, n));
     pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0],
-                      pt::ExtendOutput{true, r->d_hits, nullptr, false, false, r->exact_readbacks, nullptr, false, r->d_stack_overflow[0]},
+                      pt::ExtendOutput{true, r->d_hits, nullptr, false, false, r->exact_readbacks, nullptr, r->d_stack_overflow[0]},
                       pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
     pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(n), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids, d_t,
                               d_dirs, &r->cam);
@@ -1549,7 +1659,7 @@ int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float 
         const pt::LaunchShape g = shape_for(r, c);
         pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], r->d_counts, region_size_for(r, c));
         pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, c, 0, -1), r->q[0],
-                          pt::ExtendOutput{false, r->d_hits, nullptr, false, false, r->exact_readbacks, nullptr, false, r->d_stack_overflow[0]},
+                          pt::ExtendOutput{false, r->d_hits, nullptr, false, false, r->exact_readbacks, nullptr, r->d_stack_overflow[0]},
                           pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
         pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(c), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids,
                                   d_t, nullptr, nullptr);
@@ -1722,7 +1832,7 @@ int pt_get_stats(pt_renderer *r, pt_stats *s)
     PT_HIP(hipSetDevice(r->device));
     PT_HIP(sync_streams(r));
     drain_events(r);
-    unsigned long long c[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long c[kCounters] = {};
     PT_HIP(hipMemcpy(c, r->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     std::memset(s, 0, sizeof(*s));
     s->iterations = r->local_iterations;
@@ -1753,6 +1863,7 @@ int pt_get_stats(pt_renderer *r, pt_stats *s)
     s->shade_batches = c[13];
     s->bvh_builder = r->bvh_builder;
     s->reserved = 0;
+    s->primary_rays_culled = c[14];
     return PT_OK;
 }
 

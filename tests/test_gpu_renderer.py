@@ -335,3 +335,47 @@ def test_checkpoint_and_resume(pt, tmp_path):
     with pytest.raises(pt.PtError):
         d.load_state(path)  # truncated
     d.close()
+
+
+@pytest.mark.parametrize("name,eye,focus,size,expect", [
+    ("Box", (0.0, 1.5, 15.0), (0.0, -0.25, 0.0), (640, 360), "some"),      # the reference's pose: the box in the middle of a wide frame
+    ("Veggie", (6.0, 3.0, 12.0), (1.5, 0.5, 0.0), (333, 187), "some"),     # from the side, odd image size (strips, not tiles)
+    ("Box", (0.0, 0.5, 1.0), (0.0, 0.0, -1.0), (256, 256), "none"),        # inside the box: the bounds surround the eye
+    ("Box", (0.0, 1.5, 15.0), (0.0, 1.5, 30.0), (256, 144), "all"),        # looking away from everything
+    ("Box", (0.0, 1.5, 15.0), (9.0, -0.25, 0.0), (512, 288), "some"),      # the scene half out of the frame
+])
+def test_primary_rays_left_out_at_generation_change_nothing(pt, name, eye, focus, size, expect):
+    """Ray generation leaves out the primary rays of pixels outside the window onto which the scene's bounding
+    box and the lights project (they can only escape, frag:876).  With profile bit 2 every ray is made and
+    traced (a ray that misses everything may still be the reference's hit at t = inf).  Same sum buffer bit
+    for bit, same number of segments (a ray left out is still its path's first segment), and the count of
+    rays left out is what the pose says: some, none (eye inside the bounds), all (nothing in view)."""
+    w, h = size
+    spp, depth = 6, 5
+
+    def render(profile):
+        cam = pt.Camera(eye=eye, focus=focus, resolution=(w, h))
+        r = pt.Renderer(pt.Scene.from_arrays(**scene_arrays(name)), cam, max_depth=depth, profile=profile)
+        r.draw(spp)
+        s, st = r.read_sum(), r.stats()
+        # one-sample draws afterwards take the same path with small regions
+        r.draw(1)
+        r.draw(1)
+        s2, st2 = r.read_sum(), r.stats()
+        r.close()
+        return s, st, s2, st2
+
+    s, st, s2, st2 = render(0)
+    e, ste, e2, ste2 = render(4)
+    assert np.array_equal(s, e) and np.array_equal(s2, e2)
+    assert ste["primary_rays_culled"] == 0 and ste2["primary_rays_culled"] == 0
+    assert st["segments"] == ste["segments"] and st2["segments"] == ste2["segments"]
+    assert st["paths"] == w * h * spp and st2["paths"] == w * h * (spp + 2)
+    culled = st["primary_rays_culled"]
+    assert st2["primary_rays_culled"] * spp == culled * (spp + 2)  # the same pixels in every iteration
+    if expect == "none":
+        assert culled == 0
+    elif expect == "all":
+        assert culled == st["paths"] and not s[..., :3].any()
+    else:
+        assert 0.1 * st["paths"] < culled < 0.9 * st["paths"]
