@@ -82,6 +82,8 @@ def parse_args():
                    help="skip the pass that times every kernel alone on one stream (profiling runs: every "
                         "launch of the run is then of the overlapped kind)")
     p.add_argument("--no-extra", action="store_true", help="skip the secondary Veggie.obj measurement")
+    p.add_argument("--wide-tree", action="store_true",
+                   help="trees that are read from memory as four-wide nodes (pt_config.profile bit 5; measurement only)")
     p.add_argument("--native-reduce", action="store_true",
                    help="make the process group and the library's RCCL communicator even for one rank (what a "
                         "launch under torch.distributed.run does by itself)")
@@ -125,7 +127,7 @@ def timed_run(pt, dist, args, scene_name, rank, world, device, reducer):
     """Returns (seconds for K steps [max over ranks], renderer, samples per pixel the root holds per step)."""
     cam = pt.Camera(resolution=(args.width, args.height))
     r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
-                    iterations_per_batch=args.batch_spp, batch_streams=args.batch_streams)
+                    iterations_per_batch=args.batch_spp, batch_streams=args.batch_streams, profile=32 if args.wide_tree else 0)
     r.set_partition(rank, world)
     spp = spp_of_step(args, rank, world)
     for _ in range(args.warmup):
@@ -169,7 +171,7 @@ def kernel_profile(pt, args, scene_name, device, rank, world, batch_streams=2, c
     batch in one launch (profile bit 4), for the per-kernel breakdown."""
     cam = pt.Camera(resolution=(args.width, args.height))
     r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
-                    iterations_per_batch=args.batch_spp, profile=1 | (16 if separate_launches else 0),
+                    iterations_per_batch=args.batch_spp, profile=1 | (16 if separate_launches else 0) | (32 if args.wide_tree else 0),
                     batch_streams=batch_streams)
     r.set_partition(rank, world)
     spp = max(1, spp_of_step(args, rank, world))
@@ -186,7 +188,7 @@ def kernel_profile(pt, args, scene_name, device, rank, world, batch_streams=2, c
     # Work counters (BVH nodes fetched, triangle tests) come from a separate
     # instrumented pass so that they do not slow the timed kernels down.
     r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
-                    iterations_per_batch=args.batch_spp, profile=2)
+                    iterations_per_batch=args.batch_spp, profile=2 | (32 if args.wide_tree else 0))
     r.set_partition(rank, world)
     r.draw(min(spp, args.batch_spp))
     c = r.stats()

@@ -80,7 +80,12 @@ typedef struct {
                                       holds entries 17 and up, is used by most rays;
                                       bit 4: one launch per kernel and bounce even where all
                                       bounces of a batch would go in one launch (per-kernel
-                                      timings with bit 0; the image is the same)           */
+                                      timings with bit 0; the image is the same);
+                                      bit 5: a tree too large for on-chip memory is traversed
+                                      as four-wide nodes (two levels of the binary tree per
+                                      128-byte record): half the dependent node fetches per
+                                      ray, same hits; measured slower than the binary tree on
+                                      ten million triangles, kept for measurement             */
     uint32_t emulate_rgba8;        /* 1: beside the float sum, keep the reference's own
                                       accumulator: an 8-bit RGBA texel per pixel updated as
                                       (accum*it + sample)/(it+1) and re-quantised every

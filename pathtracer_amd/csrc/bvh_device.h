@@ -37,6 +37,17 @@ struct DeviceBvh {
 bool build_bvh_device(const float *d_vertices, const uint32_t *d_tri_vertex_ids, uint32_t n_triangles,
                       const DeviceBvhParams &params, hipStream_t stream, DeviceBvh *out, std::string *error);
 
+// The binary tree collapsed two levels at a time: one 128-byte record (a cache line) per inner node of even
+// level holding the boxes and codes of the up to four nodes two levels below it.  For trees that are read from
+// memory: a ray then waits for half as many dependent node fetches.  d_nodes: BvhNode[n_nodes] in device memory
+// (either builder's), depth as DeviceBvh / Bvh report it.  The result is hipMalloc'ed; the caller frees it.
+struct WideBvh {
+    void *d_nodes = nullptr;  // n_nodes records of 8 x float4: lo.x[4] hi.x[4] lo.y[4] hi.y[4] lo.z[4] hi.z[4] codes[4] -
+    uint32_t n_nodes = 0;
+    uint32_t depth = 0;       // four-wide nodes on the longest root-to-leaf path
+};
+bool build_wide_nodes(const void *d_nodes, uint32_t n_nodes, uint32_t depth, hipStream_t stream, WideBvh *out, std::string *error);
+
 // Sets kHitClassBit (bvh.h) in the index of every leaf-ordered triangle record whose
 // material is not purely diffuse.  d_materials: 8 floats per material (albedo rgb,
 // roughness, metallic, ...); d_material_map: material index per original triangle.

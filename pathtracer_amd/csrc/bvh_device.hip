@@ -872,6 +872,136 @@ void build_shade_records(const float *d_vertices, const uint32_t *d_tri_vertex_i
                        d_indices, d_vertex_data, d_material_map, n_triangles, static_cast<float4 *>(d_out));
 }
 
+// ------------------------------------------------------------------ four-wide nodes from the binary tree
+
+namespace {
+
+// level[i] = distance of inner node i from the root; one pass per level, top-down: the nodes of level p hand
+// p + 1 to their inner children.  (Any numbering of the node array will do.)
+__global__ void __launch_bounds__(256) k_wide_levels(const float4 *__restrict__ nodes, uint32_t n, uint32_t p, uint32_t *__restrict__ level)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n || level[i] != p) return;
+    const float4 q3 = nodes[4 * static_cast<size_t>(i) + 3];
+    const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+    if (c0 >= 0) level[c0] = p + 1u;
+    if (c1 >= 0) level[c1] = p + 1u;
+}
+
+__global__ void __launch_bounds__(256) k_wide_flags(const uint32_t *__restrict__ level, uint32_t n, uint32_t *__restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) flags[i] = (level[i] != 0xFFFFFFFFu && (level[i] & 1u) == 0u) ? 1u : 0u;
+}
+
+// One 128-byte record per inner node of even level: the up to four nodes two levels down (a child that is a
+// leaf stays as it is), as
+//   q0 = lo.x of the four, q1 = hi.x, q2 = lo.y, q3 = hi.y, q4 = lo.z, q5 = hi.z, q6 = the four child codes, q7 unused.
+// A child code >= 0 is the index of a four-wide node, < 0 a leaf code as in the binary tree.  A slot without a
+// child has the box (+inf, -inf), which no ray meets.
+__global__ void __launch_bounds__(256) k_wide_emit(const float4 *__restrict__ nodes, uint32_t n, const uint32_t *__restrict__ flags,
+                                                    const uint32_t *__restrict__ widx, float4 *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n || flags[i] == 0u) return;
+    float lo[4][3], hi[4][3];
+    int code[4];
+    uint32_t m = 0;
+    auto take = [&](const float4 *rec, int c, bool may_expand) {
+        // child c of the binary node `rec`: lo / hi as BvhNode packs them
+        const float4 a = rec[0], b = rec[1], d = rec[2], q3 = rec[3];
+        const float blo[3] = {c == 0 ? a.x : b.z, c == 0 ? a.y : b.w, c == 0 ? a.z : d.x};
+        const float bhi[3] = {c == 0 ? a.w : d.y, c == 0 ? b.x : d.z, c == 0 ? b.y : d.w};
+        const int cc = c == 0 ? __float_as_int(q3.x) : __float_as_int(q3.y);
+        (void)may_expand;
+        for (int k = 0; k < 3; ++k) lo[m][k] = blo[k], hi[m][k] = bhi[k];
+        code[m] = cc;
+        ++m;
+    };
+    const float4 *me = nodes + 4 * static_cast<size_t>(i);
+    const float4 q3 = me[3];
+    const int c01[2] = {__float_as_int(q3.x), __float_as_int(q3.y)};
+    for (int c = 0; c < 2; ++c) {
+        if (c01[c] >= 0) {
+            const float4 *child = nodes + 4 * static_cast<size_t>(c01[c]);
+            take(child, 0, false);
+            take(child, 1, false);
+        } else {
+            take(me, c, false);
+        }
+    }
+    // inner grandchildren are four-wide nodes themselves: their codes become indices into this array
+    for (uint32_t k = 0; k < m; ++k)
+        if (code[k] >= 0) code[k] = static_cast<int>(widx[code[k]]);
+    const float inf = __builtin_inff();
+    for (uint32_t k = m; k < 4u; ++k) {
+        for (int a = 0; a < 3; ++a) lo[k][a] = inf, hi[k][a] = -inf;
+        code[k] = static_cast<int>(0x80000000u);
+    }
+    float4 *o = out + 8 * static_cast<size_t>(widx[i]);
+    o[0] = make_float4(lo[0][0], lo[1][0], lo[2][0], lo[3][0]);
+    o[1] = make_float4(hi[0][0], hi[1][0], hi[2][0], hi[3][0]);
+    o[2] = make_float4(lo[0][1], lo[1][1], lo[2][1], lo[3][1]);
+    o[3] = make_float4(hi[0][1], hi[1][1], hi[2][1], hi[3][1]);
+    o[4] = make_float4(lo[0][2], lo[1][2], lo[2][2], lo[3][2]);
+    o[5] = make_float4(hi[0][2], hi[1][2], hi[2][2], hi[3][2]);
+    o[6] = make_float4(__int_as_float(code[0]), __int_as_float(code[1]), __int_as_float(code[2]), __int_as_float(code[3]));
+    o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+}  // namespace
+
+bool build_wide_nodes(const void *d_nodes, uint32_t n_nodes, uint32_t depth, hipStream_t st, WideBvh *out, std::string *error)
+{
+    *out = WideBvh();
+    if (n_nodes == 0 || !d_nodes) {
+        *error = "four-wide nodes: no tree";
+        return false;
+    }
+    Buffers buf;
+    uint32_t *level = nullptr, *flags = nullptr, *widx = nullptr, *sums = nullptr, *d_total = nullptr;
+    if (!(buf.get(&level, n_nodes) && buf.get(&flags, n_nodes) && buf.get(&widx, n_nodes) &&
+          buf.get(&sums, n_nodes / kScanTile + 2) && buf.get(&d_total, 4))) {
+        *error = "four-wide nodes: out of device memory";
+        return false;
+    }
+    const float4 *nodes = static_cast<const float4 *>(d_nodes);
+    auto fail = [&](hipError_t e) {
+        *error = std::string("four-wide nodes: ") + hipGetErrorString(e);
+        return false;
+    };
+    hipError_t e = hipMemsetAsync(level, 0xFF, static_cast<size_t>(n_nodes) * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(level, 0, 4, st);  // the root
+    if (e != hipSuccess) return fail(e);
+    for (uint32_t p = 0; p + 1 < std::max(depth, 1u); ++p)
+        hipLaunchKernelGGL(k_wide_levels, dim3(blocks_for(n_nodes, 256)), dim3(256), 0, st, nodes, n_nodes, p, level);
+    hipLaunchKernelGGL(k_wide_flags, dim3(blocks_for(n_nodes, 256)), dim3(256), 0, st, level, n_nodes, flags);
+    exclusive_scan(flags, n_nodes, widx, sums, d_total, st);
+    uint32_t n_wide = 0;
+    e = hipMemcpyAsync(&n_wide, d_total, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(e);
+    if (n_wide == 0) {
+        *error = "four-wide nodes: the tree has no root";
+        return false;
+    }
+    void *d_wide = nullptr;
+    e = hipMalloc(&d_wide, static_cast<size_t>(n_wide) * 128);
+    if (e != hipSuccess) return fail(e);
+    hipLaunchKernelGGL(k_wide_emit, dim3(blocks_for(n_nodes, 256)), dim3(256), 0, st, nodes, n_nodes, flags, widx,
+                       static_cast<float4 *>(d_wide));
+    e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        (void)hipFree(d_wide);
+        return fail(e);
+    }
+    out->d_nodes = d_wide;
+    out->n_nodes = n_wide;
+    out->depth = (depth + 1u) / 2u;
+    return true;
+}
+
 #define PT_BVH_TRY(expr)                                                                        \
     do {                                                                                        \
         const hipError_t e_ = (expr);                                                           \

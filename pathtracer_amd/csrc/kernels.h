@@ -22,6 +22,11 @@ struct SceneView {
     // Entries of a deep traversal stack (a tree read from memory) kept in LDS; 0 = the default (16).  Tests lower
     // it so that the overflow buffer is actually used (pt_config.profile bit 3).
     uint32_t deep_stack_lds_entries = 0;
+    // The tree collapsed into four-wide nodes (bvh_device.h, WideBvh), made for trees that are read from memory;
+    // null otherwise.  wide_stack_entries: stack entries a ray can need in it (3 per level + the end marker).
+    const float4 *wide_nodes = nullptr;
+    uint32_t n_wide_nodes = 0;
+    uint32_t wide_stack_entries = 0;
 };
 
 // One path queue: three 16-byte lanes per path.
@@ -124,6 +129,10 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
 // of the scene leaves): the host sizes the regions so that each of them gets the same number of regions.
 uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes,
                                bool scene_in_lds, bool overflow_buffer);
+
+// Whether the traversal kernel would read this scene's tree from memory (it does not fit in LDS): such a scene
+// gets four-wide nodes (SceneView::wide_nodes) before anything else is planned for it.
+bool extend_reads_tree_from_memory(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds);
 
 // Bytes of ExtendOutput::stack_overflow this scene's launches want (0: the stacks fit in LDS as they are).
 size_t extend_stack_overflow_bytes(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes,

@@ -484,7 +484,8 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
     // instructions per node, and following a child takes no address arithmetic.  (Records of an odd number of
     // 16-byte lanes also spread over the banks.)
     // Otherwise (SCENE_LDS == 1: the first n_lds_nodes nodes) the 64-byte records are copied as they are.
-    constexpr bool kNodeAddresses = SCENE_LDS >= 2;
+    constexpr bool kWide = SCENE_LDS == 4;  // four-wide nodes read from memory (sc.wide_nodes), nothing of the tree in LDS
+    constexpr bool kNodeAddresses = SCENE_LDS == 2 || SCENE_LDS == 3;
     constexpr uint32_t kLdsNodeBytes = kNodeAddresses ? 112u : 64u;
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     extern __shared__ float4 lds[];
@@ -499,11 +500,11 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
     // -- a near-first descent rarely has more children deferred -- and the entries above them in
     // stack_overflow[entry - lds_stack_entries][lane of the grid], so that more blocks fit on a CU.
     constexpr uint32_t kStackStep = BLOCK * sizeof(StackT);
-    constexpr bool kDeepStack = SCENE_LDS <= 1;
+    constexpr bool kDeepStack = SCENE_LDS <= 1 || kWide;
     const uint32_t lds_base = lds_address(lds_bytes);
     const uint32_t stack0 = lds_base + kLdsNodeBytes * n_lds_nodes + (SCENE_LDS == 2 ? lds_rec_bytes * sc.n_triangles : 0u) +
                             tid * static_cast<uint32_t>(sizeof(StackT));  // LDS address of the lane's entry 0
-    if (SCENE_LDS >= 1 && fill_lds) {
+    if (SCENE_LDS >= 1 && !kWide && fill_lds) {
         if (kNodeAddresses) {
             for (uint32_t i = tid; i < n_lds_nodes; i += BLOCK) {
                 const float4 n0 = sc.nodes[4 * i], n1 = sc.nodes[4 * i + 1], n2 = sc.nodes[4 * i + 2], n3 = sc.nodes[4 * i + 3];
@@ -552,7 +553,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
         f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
         float ix = 0.f, iy = 0.f, iz = 0.f, cnx = 0.f, cny = 0.f, cnz = 0.f, cfx = 0.f, cfy = 0.f, cfz = 0.f;
         bool negx = false, negy = false, negz = false;
-        uint32_t offx = 0, offy = 0, offz = 0;  // kNodeAddresses: 16 bytes on the axes along which the ray travels backwards
+        uint32_t offx = 0, offy = 0, offz = 0;  // kNodeAddresses, kWide: 16 bytes on the axes along which the ray travels backwards
         Hit h{__builtin_inff(), -1};
         float ltv = __uint_as_float(kNoLightBits);  // the word beside the ray: |ltv| = distance to the light or NaN, sign = poisoned path
         int node = kFinished;
@@ -660,7 +661,47 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                     dg[0] += 1;
                     dg[1] += __popcll(going);
                 }
-                if (go) {
+                if (kWide) {
+                  if (go) {
+                    // One 128-byte record = the four nodes two levels down: per axis the low planes of the four in
+                    // one 16-byte lane and the high planes in the next, so a ray reads its entry planes from the
+                    // lane at offset (direction negative ? 16 : 0) and its exit planes from the other one -- no
+                    // select per plane; the record is 128-byte aligned, so the offset goes into the address with an OR.
+                    const uintptr_t nb = reinterpret_cast<uintptr_t>(sc.wide_nodes) + (static_cast<uintptr_t>(static_cast<uint32_t>(node)) << 7);
+                    const float4 ex = *reinterpret_cast<const float4 *>(nb | offx), xx = *reinterpret_cast<const float4 *>(nb | (offx ^ 16u));
+                    const float4 ey = *reinterpret_cast<const float4 *>((nb | offy) + 32u), xy = *reinterpret_cast<const float4 *>((nb | (offy ^ 16u)) + 32u);
+                    const float4 ez = *reinterpret_cast<const float4 *>((nb | offz) + 64u), xz = *reinterpret_cast<const float4 *>((nb | (offz ^ 16u)) + 64u);
+                    const int4 cc = *reinterpret_cast<const int4 *>(nb + 96u);
+                    if (COUNT) ++my_nodes;
+                    // Keys: a child that is hit gets the bits of its entry distance (>= 0, so they order like the
+                    // distances) with the child's slot in the two lowest bits, a child that is missed all ones.
+                    // Sorted ascending, the nearest hit comes first and the misses last.
+#define PT_WIDE_KEY(comp, slot)                                                                                               \
+    ([&]() -> uint32_t {                                                                                                      \
+        const float tn = fmaxf(fmaxf(fmaf(ex.comp, ix, cnx), fmaf(ey.comp, iy, cny)), fmaxf(fmaf(ez.comp, iz, cnz), 0.f));    \
+        const float tf = fminf(fminf(fmaf(xx.comp, ix, cfx), fmaf(xy.comp, iy, cfy)), fminf(fmaf(xz.comp, iz, cfz), t_limit)); \
+        return tn <= tf ? ((__float_as_uint(tn) & ~3u) | slot) : 0xFFFFFFFFu;                                                 \
+    }())
+                    uint32_t k0 = PT_WIDE_KEY(x, 0u), k1 = PT_WIDE_KEY(y, 1u), k2 = PT_WIDE_KEY(z, 2u), k3 = PT_WIDE_KEY(w, 3u);
+#undef PT_WIDE_KEY
+                    auto order = [](uint32_t &a, uint32_t &b) {
+                        const uint32_t lo = min(a, b), hi = max(a, b);
+                        a = lo, b = hi;
+                    };
+                    order(k0, k1), order(k2, k3), order(k0, k2), order(k1, k3), order(k1, k2);
+                    auto code_of = [&](uint32_t key) {
+                        const uint32_t s = key & 3u;
+                        return s == 0u ? cc.x : (s == 1u ? cc.y : (s == 2u ? cc.z : cc.w));
+                    };
+                    // the nearest child is visited next, the others are deferred farthest first (so that the
+                    // nearest of them is the first to be taken up again); with no child hit the lane takes up
+                    // its last deferred child (or finds the end marker)
+                    if (k3 != 0xFFFFFFFFu) push(code_of(k3));
+                    if (k2 != 0xFFFFFFFFu) push(code_of(k2));
+                    if (k1 != 0xFFFFFFFFu) push(code_of(k1));
+                    node = k0 != 0xFFFFFFFFu ? code_of(k0) : pop();
+                  }
+                } else if (go) {
                     float e0x, x0x, e0y, x0y, e0z, x0z, e1x, x1x, e1y, x1y, e1z, x1z;
                     int c0, c1;
                     if (kNodeAddresses) {
@@ -794,8 +835,13 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
     }
 }
 
+// (Four-wide nodes are for trees read from memory, whose traversal waits for node fetches: six waves per SIMD
+// hide more of that than five, so that instantiation is held to the 80 registers six waves leave each.)
+#ifndef PT_WIDE_WAVES
+#define PT_WIDE_WAVES 6
+#endif
 template <int BLOCK, bool COUNT, bool EXACT, int SCENE_LDS, bool RENDER, bool USE_LT>
-__global__ void __launch_bounds__(BLOCK, PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
+__global__ void __launch_bounds__(BLOCK, SCENE_LDS == 4 ? PT_WIDE_WAVES : PT_EXTEND_WAVES) k_extend_bvh(SceneView sc, Regions rg, PathQueue q,
                                                         float4 *__restrict__ hit_list, float4 *__restrict__ samples,
                                                         uint32_t last_segment,
                                                         TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
@@ -1808,7 +1854,15 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
         return static_cast<size_t>(e ? std::atoi(e) : 26) * 1024;
     }();
     const uint32_t lds_entries = scene.deep_stack_lds_entries ? scene.deep_stack_lds_entries : deep_entries;
+    // Four-wide nodes (mode 4), when the scene has them: half the dependent node fetches per ray.  Nothing of the
+    // tree is kept in LDS; a ray's stack can hold three entries per level.
+    const bool wide = scene.wide_nodes != nullptr;
+    if (wide) stack_entries = std::max(stack_entries, scene.wide_stack_entries);
     const bool deep = overflow_buffer && stack_entries > lds_entries && only_block != 1024;
+    if (wide) {
+        const uint32_t in_lds = deep ? lds_entries : stack_entries;
+        return LdsPlan{256, 4, in_lds, 0, 4, static_cast<size_t>(in_lds) * 256 * sizeof(StackT)};
+    }
     if (deep) {
         LdsPlan p{256, 0, lds_entries, 0, 4, 0};
         const size_t stacks = static_cast<size_t>(lds_entries) * 256 * sizeof(StackT);
@@ -1864,6 +1918,7 @@ ExtendKernel extend_kernel(const LdsPlan &plan, bool counting, bool exact, bool 
         if (plan.mode == 3) return extend_kernel_for<1024, 3>(counting, exact, render, use_lt);
         return extend_kernel_for<1024, 1>(counting, exact, render, use_lt);
     }
+    if (plan.mode == 4) return extend_kernel_for<256, 4>(counting, exact, render, use_lt);
     if (plan.mode == 2) return extend_kernel_for<256, 2>(counting, exact, render, use_lt);
     if (plan.mode == 3) return extend_kernel_for<256, 3>(counting, exact, render, use_lt);
     if (plan.mode == 1) return extend_kernel_for<256, 1>(counting, exact, render, use_lt);
@@ -1881,10 +1936,18 @@ uint32_t extend_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t 
     return n_cus * static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(plan.block / 64);
 }
 
+bool extend_reads_tree_from_memory(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds)
+{
+    SceneView binary = scene;
+    binary.wide_nodes = nullptr;
+    return plan_lds(binary, stack_entries, n_nodes, scene_in_lds, true).mode <= 1;
+}
+
 size_t extend_stack_overflow_bytes(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes,
                                    bool scene_in_lds)
 {
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, true);
+    if (plan.mode == 4) stack_entries = std::max(stack_entries, scene.wide_stack_entries);
     if (plan.lds_stack_entries >= stack_entries) return 0;
     // the largest grid any instantiation for this plan is launched with: what a CU can hold of such blocks
     const size_t lanes = static_cast<size_t>(n_cus) * (kLdsPerCu / std::max<size_t>(plan.bytes, 1024)) * plan.block;
@@ -1921,7 +1984,7 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     const bool use_lt = out.light_distance_in_queue && scene.n_lights == 1u && !no_lt && render;
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, out.stack_overflow != nullptr);
     const uint32_t refill_at = refill_env ? static_cast<uint32_t>(refill_env)
-                                          : ((plan.mode == 0 || (plan.mode == 1 && plan.n_lds_nodes < n_nodes / 8u)) ? 32u : 16u);
+                                          : ((plan.mode == 0 || plan.mode == 4 || (plan.mode == 1 && plan.n_lds_nodes < n_nodes / 8u)) ? 32u : 16u);
     const ExtendKernel kernel = extend_kernel(plan, counting, exact_parallel, render, use_lt);
     hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block, "PT_EXT_PER_CU")), dim3(plan.block), plan.bytes, s,
                        scene, regions, q, out.hit_list, out.samples, last, tc, n_nodes, refill_at, stack_entries, plan.n_lds_nodes,
@@ -1943,6 +2006,7 @@ BouncesKernel bounces_kernel(const LdsPlan &plan, bool use_lt)
         if (plan.mode == 3) return bounces_kernel_for<1024, 3>(use_lt);
         return bounces_kernel_for<1024, 1>(use_lt);
     }
+    if (plan.mode == 4) return bounces_kernel_for<256, 4>(use_lt);
     if (plan.mode == 2) return bounces_kernel_for<256, 2>(use_lt);
     if (plan.mode == 3) return bounces_kernel_for<256, 3>(use_lt);
     if (plan.mode == 1) return bounces_kernel_for<256, 1>(use_lt);
@@ -1962,7 +2026,7 @@ uint32_t bounces_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t
 bool bounces_suit_any_batch(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds, bool overflow_buffer)
 {
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, overflow_buffer);
-    return plan.block == 256 && plan.mode >= 2;
+    return plan.block == 256 && (plan.mode == 2 || plan.mode == 3);
 }
 
 void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, const BounceLoop &loop,
@@ -1971,7 +2035,7 @@ void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32
 {
     const bool use_lt = scene.n_lights == 1u;  // raygen and shade store the light's distance beside every ray they make
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, stack_overflow != nullptr);
-    const uint32_t refill_at = (plan.mode == 0 || (plan.mode == 1 && plan.n_lds_nodes < n_nodes / 8u)) ? 32u : 16u;
+    const uint32_t refill_at = (plan.mode == 0 || plan.mode == 4 || (plan.mode == 1 && plan.n_lds_nodes < n_nodes / 8u)) ? 32u : 16u;
     const BouncesKernel kernel = bounces_kernel(plan, use_lt);
     hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block, "PT_BOUNCES_PER_CU")), dim3(plan.block), plan.bytes, s, scene, loop, n_nodes,
                        refill_at, stack_entries, plan.n_lds_nodes, plan.stride, params, plan.lds_stack_entries, stack_overflow, it_stride,

@@ -143,6 +143,7 @@ struct pt_renderer {
     // scene on the device
     pt::SceneView view{};
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_materials = nullptr, *d_lights = nullptr;
+    void *d_wide_nodes = nullptr;  // the tree as four-wide nodes, for trees that are read from memory (SceneView::wide_nodes)
     uint32_t n_nodes = 0, bvh_depth = 0, stack_entries = 16;
     double sah_cost = 0, bvh_build_ms = 0, upload_ms = 0;
 
@@ -1251,6 +1252,22 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
         hipMalloc(&r->d_params, 2 * sizeof(pt::BatchParams)) != hipSuccess)
         return bail(fail(PT_ERR_DEVICE, "hipMalloc failed"));
     if (cfg.profile & 8u) r->view.deep_stack_lds_entries = 4;  // tests: make deep stacks overflow early
+    if (cfg.use_bvh && (cfg.profile & 32u) &&
+        pt::extend_reads_tree_from_memory(r->view, r->stack_entries, r->n_nodes, r->scene_in_lds)) {
+        // A tree that is read from memory, collapsed into four-wide nodes, one cache line each: half the
+        // dependent node fetches per ray.  Opt-in (profile bit 5): measured on the 9.88 M-triangle scene it is
+        // 8-12 % slower than the binary tree -- the same bytes per ray through the CU's vector-memory path, and
+        // the ordering of four children costs more instructions than the shorter chain of fetches returns.
+        pt::WideBvh wide;
+        std::string why;
+        const double t0 = now_ms();
+        if (!pt::build_wide_nodes(r->d_nodes, r->n_nodes, r->bvh_depth, r->stream, &wide, &why)) return bail(fail(PT_ERR_DEVICE, why));
+        r->d_wide_nodes = wide.d_nodes;
+        r->view.wide_nodes = static_cast<const float4 *>(wide.d_nodes);
+        r->view.n_wide_nodes = wide.n_nodes;
+        r->view.wide_stack_entries = 3u * wide.depth + 1u;
+        r->bvh_build_ms += now_ms() - t0;
+    }
     if (cfg.use_bvh) {
         const size_t bytes = pt::extend_stack_overflow_bytes(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds);
         for (int k = 0; k < (r->two_lanes ? 2 : 1) && bytes; ++k)
@@ -1284,7 +1301,7 @@ void pt_destroy(pt_renderer *r)
     for (hipEvent_t e : {r->ev_accum[0], r->ev_accum[1], r->ev_ops})
         if (e) (void)hipEventDestroy(e);
     if (r->stream2) (void)hipStreamDestroy(r->stream2);
-    void *bufs[] = {r->d_nodes, r->d_tris, r->d_shade, r->d_materials, r->d_lights, r->d_counters, r->d_params,
+    void *bufs[] = {r->d_nodes, r->d_wide_nodes, r->d_tris, r->d_shade, r->d_materials, r->d_lights, r->d_counters, r->d_params,
                     r->d_stack_overflow[0], r->d_stack_overflow[1]};
     for (void *p : bufs)
         if (p) (void)hipFree(p);

@@ -166,12 +166,14 @@ def test_bvh_extend_equals_linear_scan_of_oracle(pt, ob, name):
     assert np.array_equal(t.view(np.uint32)[ok], ot.view(np.uint32)[ok])
 
 
-@pytest.mark.parametrize("profile", [0, 8])
+@pytest.mark.parametrize("profile", [0, 8, 32, 32 | 8])
 def test_bvh_extend_on_instanced_lattice(pt, ob, profile):
     """38 890 triangles, tree depth > 16: a deeper traversal stack, and a node array too large for LDS
     (the kernel keeps the top of the tree there and reads the rest from global memory; of each stack the
     first 16 entries are in LDS and the rest in an overflow buffer -- with profile bit 3 only the first 4,
-    so that nearly every ray goes through the overflow path).  A render must not depend on it either."""
+    so that nearly every ray goes through the overflow path).  A render must not depend on it either.
+    Profile bit 5: the same tree as four-wide nodes (two levels per record, up to three deferred children per
+    step): same hits, same image."""
     lat = _scene(pt, "Veggie").instance_lattice(10, 3)
     a = lat.arrays()
     assert lat.bvh_info()["stack_entries"] > 16
@@ -225,6 +227,11 @@ def test_bvh_extend_on_the_ten_million_triangle_scene(pt, ob):
     t, ids = r.trace_rays(o, d)
     st = r.stats()
     r.close()
+    # the same tree as four-wide nodes (profile bit 5): the same hits
+    r = pt.Renderer(lat, pt.Camera(resolution=(64, 64)), profile=32)
+    t4, ids4 = r.trace_rays(o, d)
+    r.close()
+    assert np.array_equal(ids4, ids) and np.array_equal(t4.view(np.uint32), t.view(np.uint32))
     assert st["n_triangles"] == 9_876_970 and st["bvh_depth"] <= st["stack_entries"]
     assert (oid[ok] >= 0).sum() > 40
     assert np.array_equal(ids[ok], oid[ok])

@@ -342,7 +342,7 @@ def test_checkpoint_and_resume(pt, tmp_path):
     ("Veggie", (6.0, 3.0, 12.0), (1.5, 0.5, 0.0), (333, 187), "some"),     # from the side, odd image size (strips, not tiles)
     ("Box", (0.0, 0.5, 1.0), (0.0, 0.0, -1.0), (256, 256), "none"),        # inside the box: the bounds surround the eye
     ("Box", (0.0, 1.5, 15.0), (0.0, 1.5, 30.0), (256, 144), "all"),        # looking away from everything
-    ("Box", (0.0, 1.5, 15.0), (9.0, -0.25, 0.0), (512, 288), "some"),      # the scene half out of the frame
+    ("Box", (0.0, 1.5, 15.0), (3.5, -0.25, 0.0), (512, 288), "some"),      # the scene half out of the frame
 ])
 def test_primary_rays_left_out_at_generation_change_nothing(pt, name, eye, focus, size, expect):
     """Ray generation leaves out the primary rays of pixels outside the window onto which the scene's bounding
