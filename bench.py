@@ -54,7 +54,8 @@ EXTEND_READ_PER_RAY = 32 + 4           # origin/direction lanes + light distance
 EXTEND_WRITE_PER_HIT = 16              # hit-list record of a surface hit that will be shaded
 SHADE_READ_PER_HIT = 16 + 48           # hit record + path state
 SHADE_WRITE_PER_SURVIVOR = 48 + 4      # compacted state of a surviving path + its light distance
-RAYGEN_BYTES_PER_PATH = 32 + 4         # origin / direction / seed lanes + light distance (p2 is derived, samples are tagged)
+RAYGEN_BYTES_PER_RAY = 48 + 4          # the three lanes of a primary ray that is enqueued + its light distance (rays of pixels
+                                       # outside the scene's window are never made: pt_stats.primary_rays_culled)
 SAMPLE_BYTES = 16                      # one radiance sample per path (read by accumulate)
 
 
@@ -337,7 +338,9 @@ def main():
 
         def kernel_table(p):
             shaded = p["hits_shaded"]  # surface hits handed to the shade kernel
-            extend_bytes = EXTEND_READ_PER_RAY * p["segments"] + EXTEND_WRITE_PER_HIT * shaded
+            culled = p.get("primary_rays_culled", 0)  # counted as segments, but never written nor read
+            primaries = p["paths"] - culled
+            extend_bytes = EXTEND_READ_PER_RAY * (p["segments"] - culled) + EXTEND_WRITE_PER_HIT * shaded
             shade_bytes = SHADE_READ_PER_HIT * shaded + SHADE_WRITE_PER_SURVIVOR * shaded
             table = {
                 "extend": {"ms_total": p["ms_extend"], "launches": p["launches_extend"],
@@ -346,10 +349,10 @@ def main():
                           "algorithmic_bytes": shade_bytes if p["launches_shade"] else 0},
                 # all bounces of a batch in one launch (k_bounces): the traversal and shading of every bounce
                 "bounces": {"ms_total": p["ms_bounces"], "launches": p["launches_bounces"],
-                            "algorithmic_bytes": (extend_bytes + shade_bytes + RAYGEN_BYTES_PER_PATH * p["paths"])
+                            "algorithmic_bytes": (extend_bytes + shade_bytes + RAYGEN_BYTES_PER_RAY * primaries)
                             if p["launches_bounces"] else 0},  # the kernel also makes the primary rays
                 "raygen": {"ms_total": p["ms_raygen"], "launches": p["launches_raygen"],
-                           "algorithmic_bytes": RAYGEN_BYTES_PER_PATH * p["paths"] if p["launches_raygen"] else 0},
+                           "algorithmic_bytes": RAYGEN_BYTES_PER_RAY * primaries if p["launches_raygen"] else 0},
                 "accumulate": {"ms_total": p["ms_accumulate"], "launches": p["launches_accumulate"],
                                "algorithmic_bytes": SAMPLE_BYTES * p["paths"] + 32 * n_pixels * p["launches_accumulate"]},
             }
@@ -388,8 +391,9 @@ def main():
         launches = max(1, kernels[dom]["launches"])
         flop_terms = {
             "nodes": prof["nodes_visited"] * FLOPS_PER_NODE, "triangle_tests": prof["tris_tested"] * FLOPS_PER_TRIANGLE,
-            "segments": seg * FLOPS_PER_SEGMENT, "shaded_hits": prof["hits_shaded"] * FLOPS_PER_SHADED_HIT,
-            "primary_rays": prof["paths"] * FLOPS_PER_PATH}
+            "segments": (seg - prof.get("primary_rays_culled", 0)) * FLOPS_PER_SEGMENT,
+            "shaded_hits": prof["hits_shaded"] * FLOPS_PER_SHADED_HIT,
+            "primary_rays": (prof["paths"] - prof.get("primary_rays_culled", 0)) * FLOPS_PER_PATH}
         in_kernel = {"extend": ("nodes", "triangle_tests", "segments"), "shade": ("shaded_hits",),
                      "bounces": ("nodes", "triangle_tests", "segments", "shaded_hits", "primary_rays")}[dom]
         flops_per_launch = sum(flop_terms[k] for k in in_kernel) / launches
@@ -454,6 +458,8 @@ def main():
                        "reduce_libraries": getattr(reducer, "libraries", None)},
             "msegments_per_s": value * st["segments"] / max(1, st["paths"]),
             "segments_per_path": st["segments"] / max(1, st["paths"]),
+            # primary rays of pixels outside the window the scene and the lights project to: counted as segments, never traced
+            "primary_rays_culled_per_path": st.get("primary_rays_culled", 0) / max(1, st["paths"]),
             "gates": gates,
             "roofline": roofline,
             "pipeline": {"algorithmic_bytes_per_path": bytes_per_path, "hbm_GBs_per_gpu": pipeline_gbs,

@@ -422,4 +422,34 @@ void build_bvh_best_of(const float *vertices, const uint32_t *ids, uint32_t n_tr
     }
 }
 
+void order_leaves_by_area(Bvh *bvh)
+{
+    struct Leaf {
+        double area;
+        uint32_t first, count, node, child;
+    };
+    std::vector<Leaf> leaves;
+    for (uint32_t i = 0; i < bvh->nodes.size(); ++i)
+        for (uint32_t c = 0; c < 2; ++c) {
+            const int32_t code = bvh->nodes[i].child[c];
+            if (code >= 0) continue;
+            const uint32_t bits = static_cast<uint32_t>(~code);
+            if ((bits & 7u) == 0u) continue;  // the empty second child of a one-leaf tree
+            const float *q = bvh->nodes[i].q + 6 * c;  // lo xyz, hi xyz
+            const double dx = double(q[3]) - q[0], dy = double(q[4]) - q[1], dz = double(q[5]) - q[2];
+            leaves.push_back(Leaf{dx * dy + dy * dz + dz * dx, bits >> 3, bits & 7u, i, c});
+        }
+    std::stable_sort(leaves.begin(), leaves.end(), [](const Leaf &a, const Leaf &b) {
+        return a.area != b.area ? a.area > b.area : a.first < b.first;
+    });
+    std::vector<BvhTriangle> ordered;
+    ordered.reserve(bvh->triangles.size());
+    for (const Leaf &l : leaves) {
+        const uint32_t first = static_cast<uint32_t>(ordered.size());
+        for (uint32_t k = 0; k < l.count; ++k) ordered.push_back(bvh->triangles[l.first + k]);
+        bvh->nodes[l.node].child[l.child] = leaf_code(first, l.count);
+    }
+    if (ordered.size() == bvh->triangles.size()) bvh->triangles.swap(ordered);
+}
+
 }  // namespace pt

@@ -69,6 +69,12 @@ void build_bvh(const float *vertices, const uint32_t *tri_vertex_ids, uint32_t n
 void build_bvh_best_of(const float *vertices, const uint32_t *tri_vertex_ids, uint32_t n_triangles,
                        uint32_t max_depth, Bvh *out);
 
+// Renumbers the leaves so that the leaf-ordered triangle array starts with the triangles of the leaves with the
+// largest boxes -- the leaves a random ray is most likely to reach (the surface-area heuristic's own assumption).
+// The tree is the same tree; a traversal kernel that can keep only a prefix of the triangle array in fast memory
+// (LDS) then keeps the part that is fetched most.
+void order_leaves_by_area(Bvh *bvh);
+
 // The two constants of the builder's surface-area heuristic: the largest leaf
 // and the cost of one inner-node step in units of one triangle test.
 uint32_t bvh_leaf_max();

@@ -466,7 +466,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                                             float4 *samples, uint32_t last_segment, const TraversalCounters &tc, uint32_t n_nodes,
                                             uint32_t refill_at, uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
                                             const BatchParams *bp, uint32_t lds_stack_entries,
-                                            int *stack_overflow, bool fill_lds, WaveTurns turns)
+                                            int *stack_overflow, bool fill_lds, WaveTurns turns, uint32_t n_lds_tris)
 {
     const uint32_t sample_tag = RENDER ? bp->sample_tag : 0u;
     // lds_stride: 16-byte lanes between consecutive triangle records of the LDS copy of the scene.  4 = packed: the four
@@ -491,7 +491,10 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
     extern __shared__ float4 lds[];
     char *const lds_bytes = reinterpret_cast<char *>(lds);
     float4 *lds_nodes = lds;                                                        // the first n_lds_nodes nodes
-    float4 *lds_tris = lds + (kLdsNodeBytes / 16u) * static_cast<size_t>(n_lds_nodes);  // all triangles (SCENE_LDS == 2)
+    // n_lds_tris: triangle records kept in LDS behind the nodes: all of them (SCENE_LDS == 2) or, when only the
+    // nodes fit with room to spare (SCENE_LDS == 3), the first n_lds_tris of the leaf-ordered array -- which the
+    // host has ordered so that the leaves with the largest boxes, the ones most rays come to, are at its start.
+    float4 *lds_tris = lds + (kLdsNodeBytes / 16u) * static_cast<size_t>(n_lds_nodes);
     const uint32_t lds_rec_bytes = 16u * lds_stride;
     const uint32_t tid = threadIdx.x;
     // stacks: [entry][lane]; a lane's entry e lies at stack0 + e * kStackStep.
@@ -502,7 +505,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
     constexpr uint32_t kStackStep = BLOCK * sizeof(StackT);
     constexpr bool kDeepStack = SCENE_LDS <= 1 || kWide;
     const uint32_t lds_base = lds_address(lds_bytes);
-    const uint32_t stack0 = lds_base + kLdsNodeBytes * n_lds_nodes + (SCENE_LDS == 2 ? lds_rec_bytes * sc.n_triangles : 0u) +
+    const uint32_t stack0 = lds_base + kLdsNodeBytes * n_lds_nodes + (kNodeAddresses ? lds_rec_bytes * n_lds_tris : 0u) +
                             tid * static_cast<uint32_t>(sizeof(StackT));  // LDS address of the lane's entry 0
     if (SCENE_LDS >= 1 && !kWide && fill_lds) {
         if (kNodeAddresses) {
@@ -520,8 +523,8 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
         } else {
             for (uint32_t i = tid; i < 4u * n_lds_nodes; i += BLOCK) lds_nodes[i] = sc.nodes[i];
         }
-        if (SCENE_LDS == 2)
-            for (uint32_t i = tid; i < 4u * sc.n_triangles; i += BLOCK)
+        if (kNodeAddresses)
+            for (uint32_t i = tid; i < 4u * n_lds_tris; i += BLOCK)
                 lds_tris[(i >> 2) * lds_stride + (i & 3u)] = sc.triangles[i];
         __syncthreads();
     }
@@ -761,10 +764,16 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                 const uint32_t code = ~static_cast<uint32_t>(node);
                 const uint32_t first = code >> 3, cnt = code & 7u;
                 for (uint32_t j = 0; j < cnt; ++j) {
-                    if (SCENE_LDS == 2)
+                    if (SCENE_LDS == 2) {
                         test_triangle<false>(reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(lds_tris) + __umul24(first + j, lds_rec_bytes)), o, d, h);
-                    else
+                    } else if (SCENE_LDS == 3) {
+                        // a record from LDS or from memory, lane by lane: one flat load serves both
+                        const float4 *in_lds = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(lds_tris) + __umul24(first + j, lds_rec_bytes));
+                        const float4 *in_mem = sc.triangles + 4 * static_cast<size_t>(first + j);
+                        test_triangle<false>(first + j < n_lds_tris ? in_lds : in_mem, o, d, h);
+                    } else {
                         test_triangle<false>(sc.triangles + 4 * static_cast<size_t>(first + j), o, d, h);
+                    }
                 }
                 if (COUNT) my_tris += cnt;
                 node = pop();
@@ -847,12 +856,12 @@ __global__ void __launch_bounds__(BLOCK, SCENE_LDS == 4 ? PT_WIDE_WAVES : PT_EXT
                                                         TraversalCounters tc, uint32_t n_nodes, uint32_t refill_at,
                                                         uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
                                                         const BatchParams *__restrict__ bp,
-                                                        uint32_t lds_stack_entries, int *__restrict__ stack_overflow)
+                                                        uint32_t lds_stack_entries, int *__restrict__ stack_overflow, uint32_t n_lds_tris)
 {
     const WaveTurns turns = wave_turns(rg, blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), gridDim.x * (BLOCK / 64));
     extend_body<BLOCK, COUNT, EXACT, SCENE_LDS, RENDER, USE_LT>(sc, rg, q, hit_list, samples, last_segment, tc, n_nodes, refill_at,
                                                                 stack_entries, n_lds_nodes, lds_stride, bp,
-                                                                lds_stack_entries, stack_overflow, true, turns);
+                                                                lds_stack_entries, stack_overflow, true, turns, n_lds_tris);
 }
 
 // ----------------------------------------------------------------- shade
@@ -1478,7 +1487,7 @@ template <int BLOCK, int SCENE_LDS, bool USE_LT>
 __global__ void __launch_bounds__(BLOCK, BLOCK == 256 ? 5 : 4) k_bounces(SceneView sc, BounceLoop L, uint32_t n_nodes, uint32_t refill_at,
                                                       uint32_t stack_entries, uint32_t n_lds_nodes, uint32_t lds_stride,
                                                       const BatchParams *__restrict__ bp, uint32_t lds_stack_entries,
-                                                      int *stack_overflow, uint32_t it_stride, uint32_t n_iterations)
+                                                      int *stack_overflow, uint32_t it_stride, uint32_t n_iterations, uint32_t n_lds_tris)
 {
     const TraversalCounters no_counters{nullptr, nullptr, nullptr};
     // the wave's regions are the same in every phase: where it starts and how it steps is worked out once
@@ -1495,7 +1504,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 256 ? 5 : 4) k_bounces(SceneVi
         const Regions re{rays, hits, L.n_regions, L.stride, L.size};
         extend_body<BLOCK, false, false, SCENE_LDS, true, USE_LT>(sc, re, L.q[b & 1u], L.hit_list, L.samples, last, no_counters, n_nodes,
                                                                  refill_at, stack_entries, n_lds_nodes, lds_stride, bp,
-                                                                 lds_stack_entries, stack_overflow, b == 0u, turns);
+                                                                 lds_stack_entries, stack_overflow, b == 0u, turns, n_lds_tris);
         if (last) break;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         const Regions rs{hits, L.counts + static_cast<size_t>(b + 1u) * L.pitch, L.n_regions, L.stride, L.size};
@@ -1812,6 +1821,7 @@ struct LdsPlan {
     uint32_t n_lds_nodes;
     uint32_t stride;  // 16-byte lanes per triangle record in LDS: 5 (spread over the banks) when everything wanted still fits, else 4
     size_t bytes;
+    uint32_t n_lds_tris = 0;  // leading records of the leaf-ordered triangle array kept in LDS (all of them in mode 2)
 };
 LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds, bool overflow_buffer)
 {
@@ -1824,6 +1834,7 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
         return e ? std::atoi(e) : 0;
     }();
     constexpr size_t budget_large = kLdsPerCu;
+    static const bool no_hot_tris = pt::tuning_env("PT_NO_HOT_TRIS") != nullptr;  // tuning experiments only
     auto stack_bytes = [&](int block) { return static_cast<size_t>(stack_entries) * block * sizeof(StackT); };
     // mode 2 then mode 3; within a mode small blocks before the large one, triangle records spread over the
     // banks (80 bytes) before packed ones (64).  With all nodes in LDS a node takes 112 bytes (the kernel's own
@@ -1835,8 +1846,21 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
             for (uint32_t stride : {5u, 4u}) {
                 const size_t bytes = stack_bytes(block) + static_cast<size_t>(n_nodes) * 112 +
                                      (mode == 2 ? static_cast<size_t>(scene.n_triangles) * 16 * stride : 0);
-                if (scene_in_lds && bytes <= budget) return LdsPlan{block, mode, stack_entries, n_nodes, stride, bytes};
-                if (mode == 3) break;  // no triangles in LDS: the stride changes nothing
+                if (scene_in_lds && bytes <= budget) {
+                    LdsPlan p{block, mode, stack_entries, n_nodes, stride, bytes};
+                    p.n_lds_tris = mode == 2 ? scene.n_triangles : 0u;
+                    if (mode == 3 && !no_hot_tris) {
+                        // What the nodes and the stacks leave free holds the head of the triangle array (80-byte
+                        // records), which the host orders by leaf area.  Veggie.obj: 71 of 1450 triangles in the
+                        // 5.7 KB left, traversal -2 %.  (Making more room by keeping only the first 8 entries of every
+                        // stack in LDS, the rest in the overflow buffer, was measured: the test on every push and pop
+                        // costs 9 % of the traversal, the 400 more triangles return 2.5 %.)
+                        p.n_lds_tris = std::min<uint32_t>(scene.n_triangles, static_cast<uint32_t>((budget - bytes) / (16 * stride)));
+                        p.bytes += static_cast<size_t>(p.n_lds_tris) * 16 * stride;
+                    }
+                    return p;
+                }
+                if (mode == 3) break;  // the stride of the few records that may fit changes little
             }
         }
     // The tree does not fit: it is read from memory, and the kernel waits for it.  Measured on 10 M triangles
@@ -1896,7 +1920,7 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
 
 // The instantiation of the traversal kernel for a plan and a set of switches, as a generic function pointer.
 using ExtendKernel = void (*)(SceneView, Regions, PathQueue, float4 *, float4 *, uint32_t, TraversalCounters, uint32_t, uint32_t,
-                              uint32_t, uint32_t, uint32_t, const BatchParams *, uint32_t, int *);
+                              uint32_t, uint32_t, uint32_t, const BatchParams *, uint32_t, int *, uint32_t);
 template <int BLOCK, int L>
 ExtendKernel extend_kernel_for(bool counting, bool exact, bool render, bool use_lt)
 {
@@ -1988,12 +2012,12 @@ void launch_extend(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_
     const ExtendKernel kernel = extend_kernel(plan, counting, exact_parallel, render, use_lt);
     hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block, "PT_EXT_PER_CU")), dim3(plan.block), plan.bytes, s,
                        scene, regions, q, out.hit_list, out.samples, last, tc, n_nodes, refill_at, stack_entries, plan.n_lds_nodes,
-                       plan.stride, out.params, plan.lds_stack_entries, out.stack_overflow);
+                       plan.stride, out.params, plan.lds_stack_entries, out.stack_overflow, plan.n_lds_tris);
 }
 
 namespace {
 using BouncesKernel = void (*)(SceneView, BounceLoop, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const BatchParams *, uint32_t, int *,
-                               uint32_t, uint32_t);
+                               uint32_t, uint32_t, uint32_t);
 template <int BLOCK, int L>
 BouncesKernel bounces_kernel_for(bool use_lt)
 {
@@ -2039,7 +2063,7 @@ void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32
     const BouncesKernel kernel = bounces_kernel(plan, use_lt);
     hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block, "PT_BOUNCES_PER_CU")), dim3(plan.block), plan.bytes, s, scene, loop, n_nodes,
                        refill_at, stack_entries, plan.n_lds_nodes, plan.stride, params, plan.lds_stack_entries, stack_overflow, it_stride,
-                       n_iterations);
+                       n_iterations, plan.n_lds_tris);
 }
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,

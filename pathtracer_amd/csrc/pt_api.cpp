@@ -859,9 +859,10 @@ int upload_scene(pt_renderer *r, const pt_scene_desc *sc)
     }
     if (!device_build) {
         // automatic choice: a scene small enough for the host builder gets the best of several bin counts
-        if (automatic && r->cfg.use_bvh && T < kAutoDeviceTriangles)
+        if (automatic && r->cfg.use_bvh && T < kAutoDeviceTriangles) {
             pt::build_bvh_best_of(sc->vertices, ids.data(), T, 64, &bvh);
-        else
+            pt::order_leaves_by_area(&bvh);  // what the traversal kernel keeps of the triangles in LDS is a prefix
+        } else
             pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
         if (r->cfg.use_bvh) {
             if (bvh.depth > 64) return fail(PT_ERR_STATE, "BVH deeper than the largest traversal stack");
