@@ -224,6 +224,33 @@ __global__ void __launch_bounds__(kBlock) k_raygen(SceneView sc, const BatchPara
 
 // ---------------------------------------------------------------- extend
 
+// The wave's index within its block and the region counts it reads are the same in all 64 lanes.  Said so in a
+// way the compiler can see (v_readfirstlane), everything derived from them -- the wave's turn, its region, the
+// region's base and counts, the hit-list fill counts -- lives in scalar registers and is stepped by scalar
+// instructions, and the branches on them are scalar branches instead of exec-mask manipulations.  The counts
+// are loaded by a vector load all the same (a relaxed atomic load, never a scalar load): k_bounces reads counts
+// that the same wave wrote earlier in the same launch, and the scalar cache is not coherent with vector stores.
+#ifndef PT_UNIFORM_WAVE
+#define PT_UNIFORM_WAVE 1
+#endif
+__device__ __forceinline__ uint32_t wave_in_block()
+{
+#if PT_UNIFORM_WAVE
+    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)));
+#else
+    return threadIdx.x >> 6;
+#endif
+}
+__device__ __forceinline__ uint32_t load_count(const uint32_t *p)
+{
+#if PT_UNIFORM_WAVE
+    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(
+        static_cast<int>(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+#else
+    return *p;
+#endif
+}
+
 // Region bookkeeping shared by extend and shade: which region a wave handles
 // on its k-th turn.
 __device__ __forceinline__ uint32_t region_of(const Regions &rg, uint32_t k)
@@ -372,11 +399,11 @@ __global__ void __launch_bounds__(kBlock) k_extend_scan(SceneView sc, Regions rg
     float2 *__restrict__ results = reinterpret_cast<float2 *>(hit_list);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (kBlock / 64);
-    const uint32_t k0 = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t k0 = blockIdx.x * (kBlock / 64) + wave_in_block();
     const WaveTurns turns = wave_turns(rg, k0, n_waves);
     uint32_t r = turns.r;
     for (uint32_t k = k0; k < rg.n_regions; k += n_waves, r = next_region(rg, r, turns.step)) {
-      const uint32_t n = rg.counts_in[r];
+      const uint32_t n = load_count(rg.counts_in + r);
       const uint32_t region_base = r * rg.size;
       uint32_t hit_n0 = 0, hit_n1 = 0;
       for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
@@ -544,13 +571,13 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
     // previous region are still in flight (at most two regions at a time, told
     // apart by one parity bit per lane), so only the very end of the kernel
     // runs with thinning lanes.
-    uint32_t k = blockIdx.x * (BLOCK / 64) + (tid >> 6);  // next turn of this wave
+    uint32_t k = blockIdx.x * (BLOCK / 64) + wave_in_block();  // next turn of this wave
     uint32_t cur_r = 0, cur_n = 0, cur_base = 0, cur_next = 0, cur_h0 = 0, cur_h1 = 0;  // region being handed out
     uint32_t prv_r = 0, prv_base = 0, prv_h0 = 0, prv_h1 = 0;                           // region before it
     bool cur_valid = false, prv_valid = false;
     bool cur_gen = false;  // parity of the current region; a lane whose gen differs works for the previous one
     uint32_t nxt_r = turns.r;                                          // region of turn k and its ray count
-    uint32_t nxt_n = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
+    uint32_t nxt_n = k < rg.n_regions ? load_count(rg.counts_in + nxt_r) : 0u;
     {
         // per-lane ray state
         // A lane's traversal state is `node` (>= 0: an inner node to test -- its index, or with kNodeAddresses the
@@ -602,7 +629,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                     k += n_waves;
                     // the count of the region after this one is fetched now, long before it is needed
                     nxt_r = next_region(rg, nxt_r, turns.step);
-                    nxt_n = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
+                    nxt_n = k < rg.n_regions ? load_count(rg.counts_in + nxt_r) : 0u;
                 }
             }
             if (cur_next < cur_n && (n_idle >= refill_at || n_idle == 64u)) {
@@ -874,7 +901,7 @@ __global__ void __launch_bounds__(BLOCK, SCENE_LDS == 4 ? PT_WIDE_WAVES : PT_EXT
                                                         const BatchParams *__restrict__ bp,
                                                         uint32_t lds_stack_entries, int *__restrict__ stack_overflow, uint32_t n_lds_tris)
 {
-    const WaveTurns turns = wave_turns(rg, blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), gridDim.x * (BLOCK / 64));
+    const WaveTurns turns = wave_turns(rg, blockIdx.x * (BLOCK / 64) + wave_in_block(), gridDim.x * (BLOCK / 64));
     extend_body<BLOCK, COUNT, EXACT, SCENE_LDS, RENDER, USE_LT>(sc, rg, q, hit_list, samples, last_segment, tc, n_nodes, refill_at,
                                                                 stack_entries, n_lds_nodes, lds_stride, bp,
                                                                 lds_stack_entries, stack_overflow, true, turns, n_lds_tris);
@@ -1270,9 +1297,9 @@ __device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &r
     const uint32_t sample_tag = bp->sample_tag;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
-    uint32_t k = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    uint32_t k = blockIdx.x * (BLOCK / 64) + wave_in_block();
     uint32_t nxt_r = turns.r;
-    uint32_t nxt_packed = k < rg.n_regions ? rg.counts_in[nxt_r] : 0u;
+    uint32_t nxt_packed = k < rg.n_regions ? load_count(rg.counts_in + nxt_r) : 0u;
     while (k < rg.n_regions) {
       const uint32_t r = nxt_r;
       // hits on purely diffuse surfaces from the region's first slot upwards (low half of the count),
@@ -1282,7 +1309,7 @@ __device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &r
       k += n_waves;
       if (k < rg.n_regions) {  // the next region's count is fetched while this one is shaded
           nxt_r = next_region(rg, nxt_r, turns.step);
-          nxt_packed = rg.counts_in[nxt_r];
+          nxt_packed = load_count(rg.counts_in + nxt_r);
       }
       const uint32_t n0 = packed & 0xFFFFu, n1 = packed >> 16;
       const uint32_t full0 = n0 >> 6, full1 = n1 >> 6, rem0 = n0 & 63u, rem1 = n1 & 63u;
@@ -1399,7 +1426,7 @@ __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, 
                                                    float4 *__restrict__ samples, const BatchParams *__restrict__ bp,
                                                    uint32_t final_bounce)
 {
-    const WaveTurns turns = wave_turns(rg, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), gridDim.x * (kBlock / 64));
+    const WaveTurns turns = wave_turns(rg, blockIdx.x * (kBlock / 64) + wave_in_block(), gridDim.x * (kBlock / 64));
     shade_body<kBlock>(sc, rg, in, hit_list, out, samples, bp, final_bounce, turns);
 }
 
@@ -1448,7 +1475,7 @@ __device__ __forceinline__ void raygen_regions(const SceneView &sc, const BatchP
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
     uint32_t r = turns.r;
-    for (uint32_t k = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); k < rg.n_regions; k += n_waves, r = next_region(rg, r, turns.step)) {
+    for (uint32_t k = blockIdx.x * (BLOCK / 64) + wave_in_block(); k < rg.n_regions; k += n_waves, r = next_region(rg, r, turns.step)) {
         const uint32_t base = r * rg.size, n = min(rg.size, total - base);
         uint32_t out_n = 0;  // wave-uniform: rays written to this region so far
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
@@ -1495,7 +1522,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen_regions(SceneView sc, const B
                                                             uint32_t n_iterations, PathQueue out, Regions rg, uint32_t *culled_out,
                                                             uint32_t cull)
 {
-    const WaveTurns turns = wave_turns(rg, blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), gridDim.x * (kBlock / 64));
+    const WaveTurns turns = wave_turns(rg, blockIdx.x * (kBlock / 64) + wave_in_block(), gridDim.x * (kBlock / 64));
     raygen_regions<kBlock>(sc, bp, it_stride, n_iterations, out, rg, culled_out, cull, turns);
 }
 
@@ -1510,7 +1537,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 256 ? 5 : 4) k_bounces(SceneVi
     WaveTurns turns;
     {
         const Regions rg{nullptr, L.counts, L.n_regions, L.stride, L.size};
-        turns = wave_turns(rg, blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), gridDim.x * (BLOCK / 64));
+        turns = wave_turns(rg, blockIdx.x * (BLOCK / 64) + wave_in_block(), gridDim.x * (BLOCK / 64));
         raygen_regions<BLOCK>(sc, bp, it_stride, n_iterations, L.q[0], rg, L.counts + static_cast<size_t>(2u * L.depth + 1u) * L.pitch, 1u, turns);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
