@@ -301,6 +301,7 @@ struct Hit {
 };
 constexpr int kClassBit = 1 << 30;
 constexpr int kFinished = static_cast<int>(0x80000000u);  // traversal state of a lane with nothing left to visit
+constexpr int kIdle = static_cast<int>(0x80000001u);      // ... of a lane that holds no ray (no leaf code can look like it)
 constexpr int kIdMask = kClassBit - 1;
 
 // frag:393-415 with n and dot(n,v0) hoisted (same operations, same bits).
@@ -583,8 +584,9 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
         // A lane's traversal state is `node` (>= 0: an inner node to test -- its index, or with kNodeAddresses the
         // LDS address of its record; < 0: a leaf code to test; kFinished: nothing left) and `sp`, the LDS address
         // of the first free entry of its stack.  Entry 0 of every stack holds kFinished, so the pop that finds
-        // nothing deferred yields the finished state without a test.
-        bool active = false, gen = false;
+        // nothing deferred yields the finished state without a test.  A lane without a ray stands on kIdle: whether
+        // a lane is busy is then a compare on a register the loops test anyway, not a flag of its own.
+        bool gen = false;
         uint32_t slot = 0;
         f3 o = mk(0.f, 0.f, 0.f), d = mk(0.f, 0.f, 0.f);
         float ix = 0.f, iy = 0.f, iz = 0.f, cnx = 0.f, cny = 0.f, cnz = 0.f, cfx = 0.f, cfy = 0.f, cfz = 0.f;
@@ -592,7 +594,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
         uint32_t offx = 0, offy = 0, offz = 0;  // kNodeAddresses, kWide: 16 bytes on the axes along which the ray travels backwards
         Hit h{__builtin_inff(), -1};
         float ltv = __uint_as_float(kNoLightBits);  // the word beside the ray: |ltv| = distance to the light or NaN, sign = poisoned path
-        int node = kFinished;
+        int node = kIdle;
         uint32_t sp = stack0 + kStackStep;  // LDS address of the lane's first free stack entry
         lds_store<StackT>(stack0, static_cast<StackT>(kFinished));
         const uint32_t sp_lds_end = stack0 + lds_stack_entries * kStackStep;  // addresses from here on stand for overflow entries
@@ -612,11 +614,11 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
 
         for (;;) {
             // ---- hand fresh rays to idle lanes
-            const unsigned long long idle = __ballot(!active);
+            const unsigned long long idle = __ballot(node == kIdle);
             const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
             if (n_idle >= refill_at || n_idle == 64u) {
                 // Current region dry: once the previous one has no ray in flight, publish it and open the next.
-                while (cur_next >= cur_n && k < rg.n_regions && __ballot(active && gen != cur_gen) == 0ull) {
+                while (cur_next >= cur_n && k < rg.n_regions && __ballot(node != kIdle && gen != cur_gen) == 0ull) {
                     if (RENDER && prv_valid && (tid & 63u) == 0) rg.counts_out[prv_r] = prv_h0 | (prv_h1 << 16);
                     prv_r = cur_r, prv_base = cur_base, prv_h0 = cur_h0, prv_h1 = cur_h1, prv_valid = cur_valid;
                     cur_r = nxt_r;
@@ -633,7 +635,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                 }
             }
             if (cur_next < cur_n && (n_idle >= refill_at || n_idle == 64u)) {
-                if (!active) {
+                if (node == kIdle) {
                     const uint32_t my = cur_next + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32),
                                                                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
                     if (my < cur_n) {
@@ -670,20 +672,19 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                         h.id = -1;
                         node = kNodeAddresses ? static_cast<int>(lds_base) : 0;  // the root
                         sp = stack0 + kStackStep;
-                        active = true;
                     }
                 }
                 if (COUNT) {
                 }
                 cur_next += n_idle;
             }
-            if (__ballot(active) == 0ull) {
+            if (__ballot(node != kIdle) == 0ull) {
                 if (cur_next >= cur_n && k >= rg.n_regions) break;  // nothing in flight and nothing left to hand out
                 continue;
             }
             if (COUNT) {
                 dg[4] += 1;
-                dg[5] += __popcll(__ballot(active));
+                dg[5] += __popcll(__ballot(node != kIdle));
             }
 
             // ---- phase A: inner nodes
@@ -795,7 +796,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
 
             // ---- phase B: leaves
             if (COUNT) {
-                const uint32_t c = (node != kFinished) ? ((~static_cast<uint32_t>(node)) & 7u) : 0u;
+                const uint32_t c = (node > kIdle) ? ((~static_cast<uint32_t>(node)) & 7u) : 0u;
                 uint32_t mx = c;
                 for (int off = 32; off > 0; off >>= 1) mx = max(mx, static_cast<uint32_t>(__shfl_xor(mx, off)));
                 uint32_t sm = c;
@@ -803,7 +804,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                 dg[2] += mx;
                 dg[3] += sm;
             }
-            if (node != kFinished) {
+            if (node > kIdle) {  // (no lane stands on an inner node here: what is left above kIdle is a leaf code)
                 const uint32_t code = ~static_cast<uint32_t>(node);
                 const uint32_t first = code >> 3, cnt = code & 7u;
                 for (uint32_t j = 0; j < cnt; ++j) {
@@ -827,7 +828,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
             float hit_t = 0.f;
             int hit_code = -1;
             bool other = false;
-            if (active && node == kFinished) {
+            if (node == kFinished) {
                 if (EXACT && !(h.t < __builtin_inff())) {
                     for (uint32_t j = 0; j < sc.n_triangles; ++j) {
                         const float4 *tp = sc.triangles + 4 * static_cast<size_t>(j);
@@ -858,7 +859,7 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                     // a poisoned path that escapes, or whose last allowed segment ends on a surface
                     if (!append && (__float_as_uint(ltv) & kPoisonBit)) write_poisoned_sample(samples, q.p2[slot], sample_tag);
                 }
-                active = false;
+                node = kIdle;
             }
             if (RENDER) {
                 const bool for_prev = gen != cur_gen;
@@ -1266,14 +1267,16 @@ __device__ __forceinline__ Material load_material(const SceneView &sc, uint32_t 
 
 // frag:128-147, :434-450 on one shading record: barycentric coordinates of the hit point, then the corner
 // normals weighted by them, not renormalised.
+template <bool EXACT_DIVISION = true>
 __device__ __forceinline__ f3 interpolated_normal(float4 s0, float4 s1, float4 s2, float4 s3, float4 s4, f3 p)
 {
     const f3 v0 = mk(s0.x, s0.y, s0.z), v1 = mk(s1.x, s1.y, s1.z), v2 = mk(s2.x, s2.y, s2.z);
     const f3 e0 = v1 - v0, e1 = v2 - v0, eP = p - v0;
     const float e00 = dotm(e0, e0), e01 = dotm(e0, e1), e11 = dotm(e1, e1);
     const float e0P = dotm(e0, eP), e1P = dotm(e1, eP);
-    // (a correctly rounded division, not sdiv: the primary hits' normals are compared with the reference's bit for bit)
-    const float inv = 1.f / (e00 * e11 - e01 * e01);
+    // (a correctly rounded division where the primary hits' normals are read back and compared with the reference's
+    // bit for bit; the render loop takes the shading stage's own division)
+    const float inv = EXACT_DIVISION ? 1.f / (e00 * e11 - e01 * e01) : sdiv(1.f, e00 * e11 - e01 * e01);
     const float bv = (e11 * e0P - e01 * e1P) * inv;
     const float bw = (e00 * e1P - e01 * e0P) * inv;
     const float bu = 1.f - bv - bw;
@@ -1356,7 +1359,7 @@ __device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &r
                 const f3 p = mk(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
                 const float4 *sp = sc.shade + 5 * static_cast<size_t>(code);
                 const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
-                const f3 nrm = interpolated_normal(s0, s1, s2, s3, s4, p);
+                const f3 nrm = interpolated_normal<false>(s0, s1, s2, s3, s4, p);
 
                 const float xix = rng_next(sx, sy);
                 const float xiy = rng_next(sx, sy);
