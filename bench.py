@@ -124,6 +124,10 @@ class Reducer:
         self.comm.close()
 
 
+class ReduceFailed(RuntimeError):
+    """The collective did not work on some rank (all ranks raise it together)."""
+
+
 def timed_run(pt, dist, args, scene_name, rank, world, device, reducer):
     """Returns (seconds for K steps [max over ranks], renderer, samples per pixel the root holds per step)."""
     cam = pt.Camera(resolution=(args.width, args.height))
@@ -134,7 +138,22 @@ def timed_run(pt, dist, args, scene_name, rank, world, device, reducer):
     for _ in range(args.warmup):
         r.draw(spp)
     if reducer:
-        reducer(r)  # the collective of the timed region once before it (connection set-up, kernel load)
+        # the collective of the timed region once before it (connection set-up, kernel load) -- and the place to
+        # find out that it does not work: a rank that failed alone inside the timed region would leave the others
+        # waiting at the barrier, so the ranks agree here on whether it did
+        why = ""
+        try:
+            reducer(r)
+            r.synchronize()
+        except Exception as e:  # noqa: BLE001
+            why = f"{type(e).__name__}: {e}"
+        if dist is not None:
+            reasons = [None] * world
+            dist.all_gather_object(reasons, why)
+            why = next((w for w in reasons if w), "")
+        if why:
+            r.close()
+            raise ReduceFailed(why)
     r.synchronize()
     r.reset()
     r.synchronize()
@@ -257,7 +276,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         # torch.distributed is the control plane only (communicator id, barrier, max over ranks of the time):
         # gloo on the host; the data path is the library's own RCCL reduce.
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
         if rehearsal:
             local_rank = 0
     import pathtracer_amd as pt
@@ -305,7 +326,17 @@ def main():
                 print(f"[bench] rank {rank}: no RCCL communicator ({why}); the sums go through the host", file=sys.stderr)
                 reducer = HostReduce(f"gloo on the host (RCCL communicator failed: {why})")
 
-    dt, r = timed_run(pt, dist, args, args.scene, rank, world, device, reducer)
+    try:
+        dt, r = timed_run(pt, dist, args, args.scene, rank, world, device, reducer)
+    except ReduceFailed as e:
+        # the communicator was made but the reduce itself failed: the sums go through the host, and the line says so
+        print(f"[bench] rank {rank}: the RCCL reduce failed ({e}); the sums go through the host", file=sys.stderr)
+        try:
+            reducer.close()
+        except Exception:  # noqa: BLE001
+            pass
+        reducer = HostReduce(f"gloo on the host (RCCL reduce failed: {e})")
+        dt, r = timed_run(pt, dist, args, args.scene, rank, world, device, reducer)
     st = r.stats()
     n_pixels = args.width * args.height
     spp_all_ranks = args.total_spp if args.total_spp else args.spp_per_step * world  # per step, whole job

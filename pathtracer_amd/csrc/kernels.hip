@@ -653,12 +653,13 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                         const float pad = 7.62939453125e-6f *
                                           fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), sc.scene_radius));
                         const float mx = pad * fabsf(ix), my_ = pad * fabsf(iy), mz = pad * fabsf(iz);
-                        cnx = -(o.x * ix) - mx;  // entry planes
-                        cny = -(o.y * iy) - my_;
-                        cnz = -(o.z * iz) - mz;
-                        cfx = -(o.x * ix) + mx;  // exit planes
-                        cfy = -(o.y * iy) + my_;
-                        cfz = -(o.z * iz) + mz;
+                        const float tx = o.x * ix, ty = o.y * iy, tz = o.z * iz;
+                        cnx = -tx - mx;  // entry planes
+                        cny = -ty - my_;
+                        cnz = -tz - mz;
+                        cfx = mx - tx;  // exit planes
+                        cfy = my_ - ty;
+                        cfz = mz - tz;
                         negx = ix < 0.f;
                         negy = iy < 0.f;
                         negz = iz < 0.f;
@@ -850,7 +851,8 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
                 } else if (hit_code <= -2) {
                     // passCol = attenuation * intensity (frag:878-882, :901)
                     const float4 c = q.p2[slot];
-                    const float *rad = sc.lights[-(hit_code + 2)].radiance;
+                    // (with the light's distance carried beside the ray there is exactly one light: a scalar load)
+                    const float *rad = USE_LT ? sc.lights[0].radiance : sc.lights[-(hit_code + 2)].radiance;
                     const f3 L = mk(c.x * rad[0], c.y * rad[1], c.z * rad[2]);
                     // a non-finite sample is left to the accumulate kernel (which drops and counts it)
                     samples[__float_as_uint(c.w)] = make_float4(L.x, L.y, L.z, __uint_as_float(sample_tag));

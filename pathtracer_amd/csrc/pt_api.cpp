@@ -1463,7 +1463,7 @@ int pt_load_state(pt_renderer *r, const char *path)
         // cannot check against its own (word-wise) hash: refused by name rather than as a damaged file.
         std::fclose(f);
         return fail(PT_ERR_STATE, std::string("pt_load_state: ") + path +
-                                      " is a version-1 state file (PTAMDST1); this build reads version 2 only -- render again and save");
+                                      " is a version-1 state file (PTAMDST1); this build reads versions 2 and 3 -- render again and save");
     }
     // version 3 carries two more counters (primary rays culled at generation, one spare); a version-2 file has
     // none of the former, and its render had none either

@@ -334,6 +334,12 @@ def test_checkpoint_and_resume(pt, tmp_path):
     d = _renderer(pt, "Box", 96, 64, max_depth=6)
     with pytest.raises(pt.PtError):
         d.load_state(path)  # truncated
+    # a file of the first format (no counters, another scene hash) is refused by name, not as a damaged file;
+    # one of the second format (no culled-ray counter) still loads
+    with open(path, "wb") as f:
+        f.write(b"PTAMDST1" + blob[8:])
+    with pytest.raises(pt.PtError, match="version-1"):
+        d.load_state(path)
     d.close()
 
 
