@@ -372,12 +372,14 @@ def _reference_image(name, w, h, spp, depth):
     return img.astype(np.float64)
 
 
-@pytest.mark.parametrize("name", ["Box", "Veggie"])
+@pytest.mark.parametrize("name", ["Box", "Veggie", "Box_Transmission", "Box_TransmissionSphere", "Box_Anisotropic",
+                                  "AnisotropicTest"])
 def test_image_against_reference_at_1920x1080(pt, name):
-    """The benchmark configuration itself: 1920x1080, depth 8, through the renderer's default path (all bounces
-    of a batch in one launch for Box, separate kernels on two streams for Veggie), against the reference
-    shader's float image of the same iterations 0..15 (llvmpipe takes 45 s for Box and six minutes for Veggie
-    at 16 spp).  Tolerances (relMSE = mean (I-R)^2/(R^2+0.01)), the noise floor being the relMSE between
+    """The benchmark configurations themselves (the two headline scenes and the four scenes of the transmission
+    and anisotropy configurations): 1920x1080, depth 8, through the renderer's default path (all bounces of a
+    batch in one launch for Box and the Anisotropic scenes, separate kernels on two streams for the others),
+    against the reference shader's float image of the same iterations 0..15 (llvmpipe takes half a minute to
+    six minutes per scene at 16 spp).  Tolerances (relMSE = mean (I-R)^2/(R^2+0.01)), the noise floor being the relMSE between
     two independent renders of our own (iterations 0..15 against 16..31):
       * per-pixel relMSE <= 2x the floor;
       * 16x16-box-filtered relMSE <= 2x the filtered floor, and <= 3 x 2e-4 x 256/spp (2e-4 is the filtered
@@ -401,6 +403,8 @@ def test_image_against_reference_at_1920x1080(pt, name):
     assert got <= 2.0 * floor + 1e-4, (got, floor)
     assert got_f <= 2.0 * floor_f + 1e-5, (got_f, floor_f)
     assert got_f <= 3.0 * 2.0e-4 * 256.0 / spp
+    # the same paths, not merely the same statistics: observed 4e-7 .. 7e-6 on the six scenes
+    assert got <= 1e-3 * floor, (got, floor)
     ma, mr = a.mean(axis=(0, 1)), ref.mean(axis=(0, 1))
     assert np.all(np.abs(ma - mr) <= 0.01 * mr), (ma, mr)
 
