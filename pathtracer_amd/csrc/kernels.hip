@@ -885,8 +885,23 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
             // [6] sum over waves of the time each was busy, [7] sum over launches of the longest (100 MHz ticks)
             const unsigned long long dt = wall_clock64() - t_start;
             atomicAdd(tc.diag + 6, dt);
+#ifndef PT_DIAG_BLOCK
             atomicMax(tc.diag + 7, dt);
+#endif
         }
+#ifdef PT_DIAG_BLOCK
+        // experiment: [7] = sum over blocks of the longest wave's time in the block (the slot is the start of the
+        // stack area, free once every wave of the block has finished)
+        const unsigned long long dt_wave = wall_clock64() - t_start;
+        unsigned long long *slot = reinterpret_cast<unsigned long long *>(
+            lds_bytes + kLdsNodeBytes * n_lds_nodes + (kNodeAddresses ? lds_rec_bytes * n_lds_tris : 0u));
+        __syncthreads();
+        if (tid == 0) *slot = 0ull;
+        __syncthreads();
+        if (tc.diag && (tid & 63u) == 0) atomicMax(slot, dt_wave);
+        __syncthreads();
+        if (tc.diag && tid == 0) atomicAdd(tc.diag + 7, *slot);
+#endif
     }
 }
 
