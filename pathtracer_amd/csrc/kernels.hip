@@ -808,9 +808,11 @@ __device__ __forceinline__ void extend_body(const SceneView &sc, const Regions &
             if (node > kIdle) {  // (no lane stands on an inner node here: what is left above kIdle is a leaf code)
                 const uint32_t code = ~static_cast<uint32_t>(node);
                 const uint32_t first = code >> 3, cnt = code & 7u;
+                const char *lds_tri = reinterpret_cast<const char *>(lds_tris) + __umul24(first, lds_rec_bytes);  // (SCENE_LDS == 2)
                 for (uint32_t j = 0; j < cnt; ++j) {
                     if (SCENE_LDS == 2) {
-                        test_triangle<false>(reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(lds_tris) + __umul24(first + j, lds_rec_bytes)), o, d, h);
+                        test_triangle<false>(reinterpret_cast<const float4 *>(lds_tri), o, d, h);
+                        lds_tri += lds_rec_bytes;
                     } else if (SCENE_LDS == 3) {
                         // a record from LDS or from memory, lane by lane: one flat load serves both
                         const float4 *in_lds = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(lds_tris) + __umul24(first + j, lds_rec_bytes));
@@ -1499,9 +1501,32 @@ __device__ __forceinline__ void raygen_regions(const SceneView &sc, const BatchP
         const uint32_t base = r * rg.size, n = min(rg.size, total - base);
         uint32_t out_n = 0;  // wave-uniform: rays written to this region so far
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+            // The 64 slots from base + i0 on are one 8 x 8 tile of the image when slots map to tiles (base and the
+            // number of pixels are multiples of 64 then): whether the tile lies wholly outside the window is worked
+            // out once for the wave, in scalar arithmetic, before any lane computes its pixel.
+            bool whole_tile = false;  // (wave-uniform) the tile's corner and iteration are known: x0, y0, tile_it
+            uint32_t x0 = 0, y0 = 0, tile_it = 0;
+            if (cam.map_mode == 2u && cam.div_map_units.magic != 0xFFFFFFFFu && i0 + 64u <= n) {
+                uint32_t j0, unit, tx;
+                tile_it = div_by(base + i0, n_pixels, cam.div_pixels, j0);
+                const uint32_t u = j0 >> 6;
+                if ((j0 & 63u) == 0u && u < cam.map_units) {
+                    (void)div_by(u * cam.map_stride, cam.map_units, cam.div_map_units, unit);
+                    const uint32_t ty = div_by(unit, cam.tiles_x, cam.div_tiles_x, tx);
+                    x0 = tx << 3, y0 = ty << 3;
+                    whole_tile = true;
+                    if (cull && (x0 > cam.cull_x1 || x0 + 7u < cam.cull_x0 || y0 > cam.cull_y1 || y0 + 7u < cam.cull_y0)) continue;
+                }
+            }
             bool keep = false;
             uint32_t x = 0, y = 0, it = 0, pixel = 0;
-            if (i0 + lane < n) {
+            if (whole_tile) {
+                x = x0 + (lane & 7u);
+                y = y0 + (lane >> 3);
+                it = tile_it;
+                pixel = y * cam.width + x;
+                keep = !cull || (x >= cam.cull_x0 && x <= cam.cull_x1 && y >= cam.cull_y0 && y <= cam.cull_y1);
+            } else if (i0 + lane < n) {
                 uint32_t j;
                 it = div_by(base + i0 + lane, n_pixels, cam.div_pixels, j);
                 pixel = pixel_of_slot(cam, j);
