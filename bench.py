@@ -370,9 +370,10 @@ def main():
         def kernel_table(p):
             shaded = p["hits_shaded"]  # surface hits handed to the shade kernel
             culled = p.get("primary_rays_culled", 0)  # counted as segments, but never written nor read
+            unlit = p.get("unlit_last_rays_skipped", 0)  # last-segment rays not aimed at the light: the same
             primaries = p["paths"] - culled
-            extend_bytes = EXTEND_READ_PER_RAY * (p["segments"] - culled) + EXTEND_WRITE_PER_HIT * shaded
-            shade_bytes = SHADE_READ_PER_HIT * shaded + SHADE_WRITE_PER_SURVIVOR * shaded
+            extend_bytes = EXTEND_READ_PER_RAY * (p["segments"] - culled - unlit) + EXTEND_WRITE_PER_HIT * shaded
+            shade_bytes = SHADE_READ_PER_HIT * shaded + SHADE_WRITE_PER_SURVIVOR * max(0, shaded - unlit)
             table = {
                 "extend": {"ms_total": p["ms_extend"], "launches": p["launches_extend"],
                            "algorithmic_bytes": extend_bytes if p["launches_extend"] else 0},
@@ -422,7 +423,7 @@ def main():
         launches = max(1, kernels[dom]["launches"])
         flop_terms = {
             "nodes": prof["nodes_visited"] * FLOPS_PER_NODE, "triangle_tests": prof["tris_tested"] * FLOPS_PER_TRIANGLE,
-            "segments": (seg - prof.get("primary_rays_culled", 0)) * FLOPS_PER_SEGMENT,
+            "segments": (seg - prof.get("primary_rays_culled", 0) - prof.get("unlit_last_rays_skipped", 0)) * FLOPS_PER_SEGMENT,
             "shaded_hits": prof["hits_shaded"] * FLOPS_PER_SHADED_HIT,
             "primary_rays": (prof["paths"] - prof.get("primary_rays_culled", 0)) * FLOPS_PER_PATH}
         in_kernel = {"extend": ("nodes", "triangle_tests", "segments"), "shade": ("shaded_hits",),
@@ -491,6 +492,8 @@ def main():
             "segments_per_path": st["segments"] / max(1, st["paths"]),
             # primary rays of pixels outside the window the scene and the lights project to: counted as segments, never traced
             "primary_rays_culled_per_path": st.get("primary_rays_culled", 0) / max(1, st["paths"]),
+            # rays of the last allowed segment that do not point at the light: counted as segments, never made
+            "unlit_last_rays_skipped_per_path": st.get("unlit_last_rays_skipped", 0) / max(1, st["paths"]),
             "gates": gates,
             "roofline": roofline,
             "pipeline": {"algorithmic_bytes_per_path": bytes_per_path, "hbm_GBs_per_gpu": pipeline_gbs,

@@ -142,6 +142,11 @@ typedef struct {
      * never enqueued (they can only add zero, frag:876).  They are counted in `segments` -- every path has a
      * first segment -- but no traversal kernel ever reads them. */
     uint64_t primary_rays_culled;
+    /* Rays of the paths' last allowed segment that were never made because they do not point at the scene's
+     * one light: on that segment a surface hit is not shaded and an escape is black (frag:874-897), so only
+     * reaching the light can add anything.  Counted in `segments` like the culled primary rays.  Zero with any
+     * other number of lights and with profile bit 2 / emulate_rgba8 (which shade the last surface too). */
+    uint64_t unlit_last_rays_skipped;
 } pt_stats;
 
 const char *pt_last_error(void);

@@ -116,6 +116,7 @@ class Stats(C.Structure):
         ("ms_bounces", C.c_double),
         ("launches_bounces", C.c_uint64),
         ("primary_rays_culled", C.c_uint64),
+        ("unlit_last_rays_skipped", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:

@@ -147,6 +147,9 @@ struct BounceLoop {
     uint32_t *counts;  // rows of `pitch` entries: 0..depth rays per region and bounce, depth+1..2*depth hits per region and
                        // bounce, 2*depth+1 primary rays per region that ray generation did not enqueue
     uint32_t pitch, n_regions, stride, size, depth;
+    // counter of the rays of the last allowed segment that were not made because they do not point at the scene's one
+    // light (launch_shade, unlit_skipped)
+    unsigned long long *unlit_skipped;
 };
 // Waves of k_bounces resident at once for this scene (as extend_resident_waves for the traversal kernel).
 uint32_t bounces_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds,
@@ -161,7 +164,9 @@ void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
                   const float4 *hit_list, PathQueue out, float4 *samples /* receives the sample of a path whose ray went non-finite */,
                   const BatchParams *params,
-                  bool final_bounce /* the hits of the last allowed segment: nothing survives, only non-finite samples are written */);
+                  bool final_bounce /* the hits of the last allowed segment: nothing survives, only non-finite samples are written */,
+                  unsigned long long *unlit_skipped = nullptr /* not null: the rays made here travel the last allowed segment; in a
+                  one-light scene those that do not point at the light are not written (they could add nothing) but counted here */);
 
 // The sample buffer is never cleared: a path that ends on a light writes (radiance, tag) with the tag of its
 // batch, and a slot whose w lane does not carry this batch's tag counts as a zero sample (a path that escaped).

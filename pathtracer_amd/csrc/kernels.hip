@@ -88,6 +88,9 @@ __device__ __forceinline__ float rng_next(uint32_t &sx, uint32_t &sy)
 // scene's one light, or a quiet NaN when it does not (or when the scene has another number of lights); its
 // sign bit marks a path whose throughput is no longer finite in every channel (see k_shade).
 constexpr uint32_t kNoLightBits = 0x7FC00000u;
+// What a shading pass is for (shade_body): an ordinary bounce, the hits of the last allowed segment (only
+// non-finite samples come of them), or the bounce whose rays will travel the last allowed segment.
+constexpr uint32_t kShadeBounce = 0u, kShadeFinal = 1u, kShadeBeforeLast = 2u;
 constexpr uint32_t kPoisonBit = 0x80000000u;
 
 // frag:363-382 for one light: distance along the ray to the light's rectangle,
@@ -1314,8 +1317,16 @@ __device__ __forceinline__ f3 interpolated_normal(float4 s0, float4 s1, float4 s
 template <int BLOCK>
 __device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &rg, const PathQueue &in, const float4 *hit_list,
                                            const PathQueue &out, float4 *samples, const BatchParams *bp,
-                                           uint32_t final_bounce, WaveTurns turns)
+                                           uint32_t mode, WaveTurns turns, unsigned long long *unlit_skipped)
 {
+    // mode: kShadeFinal = the hits are those of the paths' last allowed segment (see above); kShadeBeforeLast = the
+    // rays made here travel the last allowed segment, where only reaching the light can add anything (a surface
+    // hit there is not shaded, an escape is black): in a scene with one light a ray that does not point at the
+    // light's rectangle -- the light's distance beside it is NaN -- is therefore not written at all, unless its
+    // path is poisoned (then whatever ends it writes its non-finite sample).  Such rays are counted, per region,
+    // into *unlit_skipped: they are segments of their paths all the same.
+    const bool final_bounce = mode == kShadeFinal;
+    const bool drop_unlit = mode == kShadeBeforeLast && sc.n_lights == 1u;
     const uint32_t sample_tag = bp->sample_tag;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_waves = gridDim.x * (BLOCK / 64);
@@ -1340,6 +1351,7 @@ __device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &r
       const uint32_t region_base = r * rg.size;
       const uint32_t last_slot = rg.size - 1u;
       uint32_t out_n = 0;  // wave-uniform: survivors written to this region so far
+      uint32_t skipped_n = 0;  // wave-uniform: survivors not written because they cannot reach the light on their last segment
       for (uint32_t bt = 0; bt < batches; ++bt) {
         // which hit this lane takes: index from the front (take0) or from the back (take1) of the list
         bool take0 = false, take1 = false;
@@ -1425,7 +1437,17 @@ __device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &r
                 }
             }
         }
+        float tl = __uint_as_float(kNoLightBits);
+        bool unlit = false;
+        if (alive) {
+            if (sc.n_lights == 1u) tl = light_distance(sc.lights[0], mk(o0.x, o0.y, o0.z), mk(o0.w, o1.x, o1.y));
+            if (drop_unlit && !(fabsf(tl) >= 0.f) && flag == 0u) {
+                alive = false;
+                unlit = true;
+            }
+        }
         const unsigned long long live = __ballot(alive);
+        if (drop_unlit) skipped_n += static_cast<uint32_t>(__popcll(__ballot(unlit)));
         if (alive) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
@@ -1433,23 +1455,24 @@ __device__ __forceinline__ void shade_body(const SceneView &sc, const Regions &r
             out.p0[dst] = o0;
             out.p1[dst] = o1;
             out.p2[dst] = o2;
-            const float tl = sc.n_lights == 1u ? light_distance(sc.lights[0], mk(o0.x, o0.y, o0.z), mk(o0.w, o1.x, o1.y))
-                                               : __uint_as_float(kNoLightBits);
             out.lt[dst] = __uint_as_float(__float_as_uint(tl) | flag);
         }
         out_n += static_cast<uint32_t>(__popcll(live));
       }
-      if (lane == 0) rg.counts_out[r] = out_n;
+      if (lane == 0) {
+          rg.counts_out[r] = out_n;
+          if (drop_unlit && skipped_n != 0u) atomicAdd(unlit_skipped, static_cast<unsigned long long>(skipped_n));
+      }
     }
 }
 
 __global__ void __launch_bounds__(kBlock, PT_SHADE_WAVES) k_shade(SceneView sc, Regions rg, PathQueue in,
                                                    const float4 *__restrict__ hit_list, PathQueue out,
                                                    float4 *__restrict__ samples, const BatchParams *__restrict__ bp,
-                                                   uint32_t final_bounce)
+                                                   uint32_t mode, unsigned long long *__restrict__ unlit_skipped)
 {
     const WaveTurns turns = wave_turns(rg, blockIdx.x * (kBlock / 64) + wave_in_block(), gridDim.x * (kBlock / 64));
-    shade_body<kBlock>(sc, rg, in, hit_list, out, samples, bp, final_bounce, turns);
+    shade_body<kBlock>(sc, rg, in, hit_list, out, samples, bp, mode, turns, unlit_skipped);
 }
 
 // ------------------------------------------------- all bounces in one launch
@@ -1596,7 +1619,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 256 ? 5 : 4) k_bounces(SceneVi
         if (last) break;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         const Regions rs{hits, L.counts + static_cast<size_t>(b + 1u) * L.pitch, L.n_regions, L.stride, L.size};
-        shade_body<BLOCK>(sc, rs, L.q[b & 1u], L.hit_list, L.q[(b + 1u) & 1u], L.samples, bp, 0u, turns);
+        shade_body<BLOCK>(sc, rs, L.q[b & 1u], L.hit_list, L.q[(b + 1u) & 1u], L.samples, bp,
+                          b + 2u == L.depth ? kShadeBeforeLast : kShadeBounce, turns, L.unlit_skipped);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 }
@@ -2156,10 +2180,11 @@ void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32
 
 void launch_shade(hipStream_t s, LaunchShape g, const SceneView &scene, Regions regions, PathQueue in,
                   const float4 *hit_list, PathQueue out, float4 *samples, const BatchParams *params,
-                  bool final_bounce)
+                  bool final_bounce, unsigned long long *unlit_skipped)
 {
+    const uint32_t mode = final_bounce ? kShadeFinal : (unlit_skipped ? kShadeBeforeLast : kShadeBounce);
     hipLaunchKernelGGL(k_shade, dim3(resident_grid(k_shade, 0, g, kBlock, "PT_SHADE_PER_CU")), dim3(kBlock), 0, s, scene, regions, in, hit_list, out,
-                       samples, params, final_bounce ? 1u : 0u);
+                       samples, params, mode, unlit_skipped);
 }
 
 void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, float4 *sum, uint32_t n_pixels,

@@ -654,7 +654,8 @@ void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
     const bool exact_samples = r->cfg.emulate_rgba8 || (r->cfg.profile & 4u);
     if (bounces_in_one_launch(r, n_paths)) {
         const pt::Regions rg = regions_for(r, n_paths, 0, -1, d_counts);
-        pt::BounceLoop loop{{q[0], q[1]}, d_hits, d_samples, d_counts, r->region_pitch, rg.n_regions, rg.stride, rg.size, depth};
+        pt::BounceLoop loop{{q[0], q[1]}, d_hits, d_samples, d_counts, r->region_pitch, rg.n_regions, rg.stride, rg.size, depth,
+                            r->d_counters + 15};
         Timed t(r, 4, st);
         pt::launch_bounces(st, g, r->view, r->stack_entries, loop, bp, r->n_nodes, r->scene_in_lds, r->d_stack_overflow[lane], r->world, kb);
         return;
@@ -680,10 +681,14 @@ void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
                               eo, tc, r->n_nodes, r->scene_in_lds);
         }
         if (!last) {
+            // The rays this bounce makes for the last allowed segment can only matter if they reach the light (a
+            // surface hit there is not shaded): with one light, those that do not point at it are not made.  Not
+            // with the exact-samples pass, which does shade the last surface.
+            const bool before_last = (b + 2 == depth) && !exact_samples && r->view.n_lights == 1u;
             Timed t(r, 2, st);
             pt::launch_shade(st, g, r->view,
                              regions_for(r, n_paths, static_cast<uint32_t>(hit_row), static_cast<int>(b) + 1, d_counts), in, d_hits,
-                             out, d_samples, bp, final_shade);
+                             out, d_samples, bp, final_shade, before_last ? r->d_counters + 15 : nullptr);
         }
     }
 }
@@ -1882,6 +1887,8 @@ int pt_get_stats(pt_renderer *r, pt_stats *s)
     s->bvh_builder = r->bvh_builder;
     s->reserved = 0;
     s->primary_rays_culled = c[14];
+    s->unlit_last_rays_skipped = c[15];
+    s->segments += c[15];  // (they are segments of their paths all the same)
     return PT_OK;
 }
 
