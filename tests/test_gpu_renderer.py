@@ -385,3 +385,41 @@ def test_primary_rays_left_out_at_generation_change_nothing(pt, name, eye, focus
         assert culled == st["paths"] and not s[..., :3].any()
     else:
         assert 0.1 * st["paths"] < culled < 0.9 * st["paths"]
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 8])
+@pytest.mark.parametrize("name", ["Box", "Veggie"])
+def test_last_segment_rays_that_cannot_reach_the_light_change_nothing(pt, name, depth):
+    """On a path's last allowed segment only reaching the light adds anything (a surface hit there is not shaded,
+    an escape is black, frag:874-897): in a one-light scene the rays of that segment that do not point at the
+    light are not made.  With profile bit 2 (which shades the last surface too) every ray is made.  Same sum
+    buffer bit for bit, same number of segments; rays are skipped from depth 2 on, and none with two lights."""
+    w, h, spp = 256, 144, 5
+
+    def render(profile, lights=1):
+        scene = pt.Scene.from_arrays(**scene_arrays(name))
+        if lights == 2:
+            scene.set_lights([pt.make_light((4, 4, 4), (0, 1.95, 0), (3.14 / 2, 0, 0), (1.25, 1.25, 1)),
+                              pt.make_light((2, 1, 1), (1.0, 0.5, 1.5), (0.3, 0.2, 0.1), (0.5, 0.5, 1))])
+        r = pt.Renderer(scene, pt.Camera(resolution=(w, h)), max_depth=depth, profile=profile)
+        r.draw(spp)
+        r.draw(1)  # a one-sample draw takes the one-launch path with small regions
+        s, st = r.read_sum(), r.stats()
+        r.close()
+        return s, st
+
+    s, st = render(0)
+    e, ste = render(4)
+    assert np.array_equal(s, e)
+    assert st["segments"] == ste["segments"]
+    assert ste["unlit_last_rays_skipped"] == 0
+    if depth == 1:
+        assert st["unlit_last_rays_skipped"] == 0
+    else:
+        # most rays of the last segment do not point at the light
+        assert 0 < st["unlit_last_rays_skipped"] < st["paths"]
+    if depth == 3 and name == "Box":
+        s2, st2 = render(0, lights=2)
+        e2, ste2 = render(4, lights=2)
+        assert np.array_equal(s2, e2) and st2["segments"] == ste2["segments"] and st2["unlit_last_rays_skipped"] == 0
+
