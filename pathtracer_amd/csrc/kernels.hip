@@ -2171,7 +2171,12 @@ void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32
 {
     const bool use_lt = scene.n_lights == 1u;  // raygen and shade store the light's distance beside every ray they make
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, stack_overflow != nullptr);
-    const uint32_t refill_at = (plan.mode == 0 || plan.mode == 4 || (plan.mode == 1 && plan.n_lds_nodes < n_nodes / 8u)) ? 32u : 16u;
+    static const int refill_env = [] {
+        const char *e = pt::tuning_env("PT_REFILL");  // tuning experiments only
+        return e ? std::atoi(e) : 0;
+    }();
+    const uint32_t refill_at = refill_env ? static_cast<uint32_t>(refill_env)
+                                          : ((plan.mode == 0 || plan.mode == 4 || (plan.mode == 1 && plan.n_lds_nodes < n_nodes / 8u)) ? 32u : 16u);
     const BouncesKernel kernel = bounces_kernel(plan, use_lt);
     hipLaunchKernelGGL(kernel, dim3(resident_grid(kernel, plan.bytes, g, plan.block, "PT_BOUNCES_PER_CU")), dim3(plan.block), plan.bytes, s, scene, loop, n_nodes,
                        refill_at, stack_entries, plan.n_lds_nodes, plan.stride, params, plan.lds_stack_entries, stack_overflow, it_stride,
