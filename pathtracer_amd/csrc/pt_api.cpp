@@ -21,73 +21,13 @@
 
 #include "bvh.h"
 #include "bvh_device.h"
-#include "camera.h"
-#include "device_types.h"
-#include "kernels.h"
-#include "renderer_internal.h"
-#include "scene.h"
+#include "renderer_state.h"
+
+using namespace pt_internal;
 
 namespace {
 
 thread_local std::string g_last_error;
-
-// Staging memory of pt_read_tonemapped_noalloc: the 8-bit RGB image the tone-map kernel writes before it is
-// copied to the caller.  A file-scope device array instead of a hipMalloc per call, for callers that must not
-// allocate.  Every GPU the library runs on holds its own copy of the array, at its own address, until the
-// process ends; in host code the name below is only a handle for hipGetSymbolAddress, never a device address.
-constexpr size_t kNoAllocMaxPixels = size_t(2560) * 1440;
-constexpr size_t kNoAllocScratchBytes = 3 * kNoAllocMaxPixels;  // 10.5 MiB per GPU
-static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
-
-constexpr int kMaxDevices = 64;
-std::mutex g_scratch_mutex;
-unsigned char *g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU, set by scratch_init
-
-// Looks up the address of `scratch` on `device`, which must be the current device; once per device.
-hipError_t scratch_init(int device)
-{
-    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
-    std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (g_scratch_ptr[device]) return hipSuccess;
-    void *ptr = nullptr;
-    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
-    if (e != hipSuccess) return e;
-    if (!ptr) return hipErrorInvalidSymbol;
-    g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
-    return hipSuccess;
-}
-
-int fail(int code, const std::string &msg)
-{
-    g_last_error = msg;
-    return code;
-}
-
-#define PT_HIP(expr)                                                                                    \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess)                                                                           \
-            return fail(PT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" +      \
-                                           __FILE__ + ":" + std::to_string(__LINE__) + ")");            \
-    } while (0)
-
-#define PT_REQUIRE(cond, msg) \
-    do {                      \
-        if (!(cond)) return fail(PT_ERR_INVALID, msg); \
-    } while (0)
-
-// Entry points that touch the path buffers refuse a renderer whose last pt_resize left it without any.
-#define PT_USABLE(r)                                                                                              \
-    do {                                                                                                          \
-        if (!(r)->usable)                                                                                         \
-            return fail(PT_ERR_STATE, "the renderer has no image buffers (a pt_resize failed); call pt_resize again"); \
-    } while (0)
-
-double now_ms()
-{
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
 
 // Inverse of a column-major f32 4x4 evaluated in float64 and rounded to f32
 // (the shader inverts per ray, pathtracer.frag.glsl:102; the float64 inverse
@@ -123,106 +63,14 @@ bool invert_mat4(const float m[16], float inv[16])
 
 }  // namespace
 
-struct pt_scene {
-    pt::Scene scene;
-};
+namespace pt_internal {
 
-struct pt_camera {
-    pt::Camera cam;
-    explicit pt_camera(const pt::Camera &c) : cam(c) {}
-};
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
 
-constexpr size_t kCounters = 16;  // device counters behind pt_stats (pt_renderer::d_counters)
-
-struct pt_renderer {
-    pt_config cfg{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    uint32_t n_cus = 256;
-
-    // scene on the device
-    pt::SceneView view{};
-    void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_materials = nullptr, *d_lights = nullptr;
-    void *d_wide_nodes = nullptr;  // the tree as four-wide nodes, for trees that are read from memory (SceneView::wide_nodes)
-    uint32_t n_nodes = 0, bvh_depth = 0, stack_entries = 16;
-    double sah_cost = 0, bvh_build_ms = 0, upload_ms = 0;
-
-    // camera
-    pt::DeviceCamera cam{};
-
-    // path state
-    bool usable = true;  // false after a pt_resize that could neither get the new buffers nor restore the old size
-    uint32_t width = 0, height = 0, batch_iterations = 1;
-    size_t capacity = 0;
-    pt::PathQueue q[2] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
-    float4 *d_hits = nullptr;                 // hit list of the render loop; (t, code) results of the readbacks
-    float4 *d_samples = nullptr;
-    uint32_t sample_tag = 0;                  // batch counter; tags the samples written in the current batch
-    float4 *d_sum = nullptr;
-    uint32_t *d_counts = nullptr;             // (max_depth + 1) rows of region_pitch live counts, one row per bounce
-    uint32_t region_pitch = 0;                // regions the queues hold at full capacity
-    uint32_t region_size = 1024;              // slots per region, chosen from the batch size and the resident waves
-    uint32_t region_size_env = 0;             // set through the environment (experiments)
-    uint32_t extend_waves = 0;                // waves of the traversal kernel resident at once
-    uint32_t bounces_waves = 0;               // the same for the kernel that runs all bounces of a batch in one launch
-    bool bounces_any_size = false;            // that kernel serves this scene best at every batch size (kernels.h)
-    uint64_t scene_hash = 0;                  // FNV-1a over the scene arrays (checkpoint compatibility)
-    uint8_t *d_rgba8 = nullptr;               // emulated 8-bit accumulation texture (cfg.emulate_rgba8)
-    uint32_t bvh_builder = 0;                 // the builder that made the tree (0 host, 1 device)
-
-    // Second set of batch buffers with a stream of its own.  Consecutive batches alternate between the
-    // two sets, so that the kernels of two batches are in flight together: the traversal kernel is bound by
-    // VALU issue and the shade / raygen / accumulate kernels by HBM, and a kernel's thinning tail is filled
-    // by the other batch's work.  Only the accumulate kernels are ordered against each other (events), in
-    // batch order, so the image is the one a single stream produces.
-    bool two_lanes = false;
-    hipStream_t stream2 = nullptr;
-    pt::PathQueue q2[2] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
-    float4 *d_hits2 = nullptr, *d_samples2 = nullptr;
-    uint32_t *d_counts2 = nullptr;
-    uint32_t sample_tag2 = 0;
-    hipEvent_t ev_accum[2] = {nullptr, nullptr};  // recorded after a set's accumulate kernel
-    bool ev_accum_set[2] = {false, false};
-    hipEvent_t ev_ops = nullptr;                  // recorded on `stream` after work the second stream must wait for
-    bool ops_pending = false;
-    uint32_t next_lane = 0;
-    uint32_t lanes_in_use = 1;                    // 2 unless the second set did not fit in memory
-    bool scene_in_lds = true;                 // extend keeps nodes (and triangles) in LDS when they fit
-    unsigned long long *d_counters = nullptr; // kCounters words: [0] segments [1] nan samples [2] nodes visited [3] tris tested [4..11] extend diagnostics [12] hits shaded [13] shade batches [14] primary rays culled at generation [15] spare
-
-    // pt_read_hit_ids / pt_trace_rays report hits at t = +inf on exactly
-    // parallel triangles like the reference does (see k_extend_bvh).
-    bool exact_readbacks = true;
-
-    // progress
-    uint32_t rank = 0, world = 1;
-    uint64_t local_iterations = 0;  // samples per pixel rendered by this renderer since reset
-    uint64_t paths = 0;
-
-    // profile
-    double ms[5] = {0, 0, 0, 0, 0};
-    uint64_t launches[5] = {0, 0, 0, 0, 0};
-    struct TimedLaunch {
-        hipEvent_t begin, end;
-        int kernel;  // 0 raygen, 1 extend, 2 shade, 3 accumulate, 4 all bounces in one launch
-    };
-    std::vector<TimedLaunch> timed;
-
-    // per-batch scalars on the device, one block per set of batch buffers (kernels.h, BatchParams)
-    pt::BatchParams *d_params = nullptr;
-
-    // World-space points whose projections bound everything a primary ray can meet: the corners of the mesh's
-    // bounding box and of every light's rectangle (update_cull_window).
-    std::vector<std::array<double, 3>> cull_points;
-
-    // the deep ends of the traversal kernel's stacks for a tree that is read from memory (kernels.h,
-    // ExtendOutput::stack_overflow): one buffer per stream, null when the stacks fit in LDS
-    int *d_stack_overflow[2] = {nullptr, nullptr};
-};
-
-namespace {
-
-// Waits for everything the renderer has enqueued, on both of its streams.
 hipError_t sync_streams(pt_renderer *r)
 {
     hipError_t e = hipSuccess;
@@ -230,6 +78,10 @@ hipError_t sync_streams(pt_renderer *r)
     const hipError_t e1 = r->stream ? hipStreamSynchronize(r->stream) : hipSuccess;
     return e != hipSuccess ? e : e1;
 }
+
+}  // namespace pt_internal
+
+namespace {
 
 // Work just enqueued on the main stream touches what the second stream's next batch uses (the sum buffer,
 // the counters): that batch will wait for it.
@@ -448,6 +300,10 @@ bool bounces_in_one_launch(const pt_renderer *r, size_t n_paths)
            (n_paths <= fused_max_paths || (r->bounces_any_size && !never_any_size));
 }
 
+}  // namespace
+
+namespace pt_internal {
+
 // Slots per region for a launch over n_items queue slots.  A full batch uses the size the buffers were laid out
 // for; a smaller one (the reference's one sample per draw) gets smaller regions, so that it still spreads over
 // all resident waves: the same rule as in alloc_paths, within what the count rows and the hit list can hold.
@@ -480,7 +336,7 @@ uint32_t region_size_for(const pt_renderer *r, size_t n_items)
 // regions (k * stride) mod n_regions, k = w, w + n_waves, ...; a stride near
 // the golden ratio of n_regions, coprime to it, scatters neighbouring image
 // areas over different waves.
-pt::Regions regions_for(const pt_renderer *r, size_t n_items, uint32_t row_in, int row_out, uint32_t *counts = nullptr)
+pt::Regions regions_for(const pt_renderer *r, size_t n_items, uint32_t row_in, int row_out, uint32_t *counts)
 {
     if (!counts) counts = r->d_counts;
     pt::Regions g;
@@ -503,6 +359,10 @@ pt::LaunchShape shape_for(const pt_renderer *r, size_t work_items)
     return pt::LaunchShape{static_cast<uint32_t>(std::max<size_t>(1, std::min(blocks_needed, cap))), r->n_cus,
                            static_cast<uint32_t>(std::max<size_t>(1, regions))};
 }
+
+}  // namespace pt_internal
+
+namespace {
 
 // The window of pixels outside of which no primary ray can meet the scene's bounds or a light
 // (DeviceCamera::cull_*; kernels.hip, raygen_regions).  A pixel's rays go through image-plane points
@@ -582,6 +442,10 @@ void update_cull_window(pt_renderer *r)
     c.cull_y1 = static_cast<uint32_t>(uy);
 }
 
+}  // namespace
+
+namespace pt_internal {
+
 int reset_accumulation(pt_renderer *r)
 {
     update_cull_window(r);  // every change of camera, size or scene lights comes through here
@@ -598,6 +462,10 @@ int reset_accumulation(pt_renderer *r)
     }
     return PT_OK;
 }
+
+}  // namespace pt_internal
+
+namespace {
 
 // Brackets one launch with events when profiling is on.
 struct Timed {
@@ -1007,7 +875,11 @@ bool sum_buffer(pt_renderer *r, SumBuffer *out)
 
 void main_stream_work_enqueued(pt_renderer *r) { mark_main_stream_work(r); }
 
-int set_error(int code, const std::string &msg) { return fail(code, msg); }
+int set_error(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
 
 }  // namespace pt_internal
 
@@ -1023,166 +895,6 @@ int pt_device_count(void)
     if (e != hipSuccess) return fail(PT_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
     return n;
 }
-
-/* ------------------------------------------------------------------ Scene */
-
-int pt_scene_load_obj(const char *obj_path, const char *mtl_root, pt_scene **out)
-{
-    PT_REQUIRE(obj_path && out, "pt_scene_load_obj: null argument");
-    pt_scene *s = new (std::nothrow) pt_scene{pt::Scene(obj_path, mtl_root)};
-    if (!s) return fail(PT_ERR_INVALID, "out of memory");
-    if (!s->scene.m_error.empty() && s->scene.m_vertices.empty()) {
-        std::string msg = s->scene.m_error;
-        delete s;
-        return fail(PT_ERR_IO, msg);
-    }
-    *out = s;
-    return PT_OK;
-}
-
-int pt_scene_create_default(pt_scene **out)
-{
-    PT_REQUIRE(out, "pt_scene_create_default: null argument");
-    *out = new pt_scene{pt::Scene()};
-    return PT_OK;
-}
-
-int pt_scene_from_desc(const pt_scene_desc *d, pt_scene **out)
-{
-    PT_REQUIRE(d && out, "pt_scene_from_desc: null argument");
-    pt_scene *s = new pt_scene{pt::Scene()};
-    pt::Scene &sc = s->scene;
-    sc.m_vertices.assign(reinterpret_cast<const pt::Vec3 *>(d->vertices),
-                         reinterpret_cast<const pt::Vec3 *>(d->vertices) + d->n_vertices);
-    sc.m_indices.assign(reinterpret_cast<const pt::Vec4 *>(d->indices),
-                        reinterpret_cast<const pt::Vec4 *>(d->indices) + d->n_triangles);
-    sc.m_vertexData.assign(reinterpret_cast<const pt::Scene::VertexData *>(d->vertex_data),
-                           reinterpret_cast<const pt::Scene::VertexData *>(d->vertex_data) + 3 * static_cast<size_t>(d->n_triangles));
-    sc.m_lights.assign(reinterpret_cast<const pt::Scene::Light *>(d->lights),
-                       reinterpret_cast<const pt::Scene::Light *>(d->lights) + d->n_lights);
-    sc.m_lightCount[0] = d->n_lights;
-    sc.m_materials.assign(reinterpret_cast<const pt::Scene::Material *>(d->materials),
-                          reinterpret_cast<const pt::Scene::Material *>(d->materials) + d->n_materials);
-    sc.m_materialMap.assign(d->material_map, d->material_map + d->n_triangles);
-    *out = s;
-    return PT_OK;
-}
-
-void pt_scene_destroy(pt_scene *scene) { delete scene; }
-
-int pt_scene_get_desc(const pt_scene *scene, pt_scene_desc *d)
-{
-    PT_REQUIRE(scene && d, "pt_scene_get_desc: null argument");
-    const pt::Scene &sc = scene->scene;
-    d->vertices = sc.m_vertices.empty() ? nullptr : &sc.m_vertices[0].x;
-    d->n_vertices = static_cast<uint32_t>(sc.m_vertices.size());
-    d->indices = sc.m_indices.empty() ? nullptr : &sc.m_indices[0].x;
-    d->n_triangles = static_cast<uint32_t>(sc.m_indices.size());
-    d->vertex_data = sc.m_vertexData.empty() ? nullptr : &sc.m_vertexData[0].normal.x;
-    d->lights = sc.m_lights.empty() ? nullptr : sc.m_lights[0].radiance;
-    d->n_lights = std::min<uint32_t>(sc.m_lightCount[0], static_cast<uint32_t>(sc.m_lights.size()));
-    d->materials = sc.m_materials.empty() ? nullptr : &sc.m_materials[0].albedo.x;
-    d->n_materials = static_cast<uint32_t>(sc.m_materials.size());
-    d->material_map = sc.m_materialMap.empty() ? nullptr : sc.m_materialMap.data();
-    return PT_OK;
-}
-
-int pt_light_make(const float radiance[3], const float position[3], const float rotation[3], const float scale[3],
-                  float out_light[20])
-{
-    PT_REQUIRE(radiance && position && rotation && scale && out_light, "pt_light_make: null argument");
-    pt::Scene::Light l(pt::make3(radiance[0], radiance[1], radiance[2]), pt::make3(position[0], position[1], position[2]),
-                       pt::make3(rotation[0], rotation[1], rotation[2]), pt::make3(scale[0], scale[1], scale[2]));
-    std::memcpy(out_light, &l, sizeof(l));
-    return PT_OK;
-}
-
-int pt_scene_set_lights(pt_scene *scene, const float *lights, uint32_t n)
-{
-    PT_REQUIRE(scene && (lights || n == 0), "pt_scene_set_lights: null argument");
-    scene->scene.m_lights.assign(reinterpret_cast<const pt::Scene::Light *>(lights),
-                                 reinterpret_cast<const pt::Scene::Light *>(lights) + n);
-    scene->scene.m_lightCount[0] = n;
-    return PT_OK;
-}
-
-int pt_scene_set_default_light(pt_scene *scene)
-{
-    PT_REQUIRE(scene, "pt_scene_set_default_light: null argument");
-    scene->scene.setDefaultLight();
-    return PT_OK;
-}
-
-int pt_scene_instance_lattice(const pt_scene *base, uint32_t room_triangles, uint32_t n, pt_scene **out)
-{
-    PT_REQUIRE(base && out && n >= 1, "pt_scene_instance_lattice: bad argument");
-    const size_t nv = base->scene.m_vertices.size() * (static_cast<size_t>(n) * n * n + 1);
-    PT_REQUIRE(nv < (size_t(1) << 24), "pt_scene_instance_lattice: more than 2^24 vertices");
-    *out = new pt_scene{pt::Scene::instanceLattice(base->scene, room_triangles, n)};
-    return PT_OK;
-}
-
-/* ----------------------------------------------------------------- Camera */
-
-int pt_camera_create(const float eye[3], const float focus[3], uint32_t width, uint32_t height, pt_camera **out)
-{
-    PT_REQUIRE(eye && focus && out, "pt_camera_create: null argument");
-    *out = new pt_camera(pt::Camera(pt::make3(eye[0], eye[1], eye[2]), pt::make3(focus[0], focus[1], focus[2]), width, height));
-    return PT_OK;
-}
-void pt_camera_destroy(pt_camera *cam) { delete cam; }
-int pt_camera_look_at(pt_camera *cam, const float focus[3], const float *eye)
-{
-    PT_REQUIRE(cam && focus, "pt_camera_look_at: null argument");
-    if (eye)
-        cam->cam.lookAt(pt::make3(focus[0], focus[1], focus[2]), pt::make3(eye[0], eye[1], eye[2]));
-    else
-        cam->cam.lookAt(pt::make3(focus[0], focus[1], focus[2]));
-    return PT_OK;
-}
-int pt_camera_move(pt_camera *cam, const float o[3])
-{
-    PT_REQUIRE(cam && o, "pt_camera_move: null argument");
-    cam->cam.move(pt::make3(o[0], o[1], o[2]));
-    return PT_OK;
-}
-int pt_camera_pan(pt_camera *cam, float dx, float dy)
-{
-    PT_REQUIRE(cam, "pt_camera_pan: null argument");
-    cam->cam.pan(dx, dy);
-    return PT_OK;
-}
-int pt_camera_orbit(pt_camera *cam, float dx, float dy)
-{
-    PT_REQUIRE(cam, "pt_camera_orbit: null argument");
-    cam->cam.orbit(dx, dy);
-    return PT_OK;
-}
-int pt_camera_zoom(pt_camera *cam, float scale)
-{
-    PT_REQUIRE(cam, "pt_camera_zoom: null argument");
-    cam->cam.zoom(scale);
-    return PT_OK;
-}
-int pt_camera_update(pt_camera *cam)
-{
-    PT_REQUIRE(cam, "pt_camera_update: null argument");
-    cam->cam.update();
-    return PT_OK;
-}
-int pt_camera_get(const pt_camera *cam, float out[15], uint32_t res[2])
-{
-    PT_REQUIRE(cam && out, "pt_camera_get: null argument");
-    const pt::Vec3 v[5] = {cam->cam.m_eye, cam->cam.m_focus, cam->cam.m_forward, cam->cam.m_up, cam->cam.m_right};
-    for (int i = 0; i < 5; ++i)
-        for (int k = 0; k < 3; ++k) out[3 * i + k] = v[i][k];
-    if (res) {
-        res[0] = cam->cam.m_resolution[0];
-        res[1] = cam->cam.m_resolution[1];
-    }
-    return PT_OK;
-}
-
 /* --------------------------------------------------------------- Renderer */
 
 void pt_config_default(pt_config *cfg)
@@ -1224,7 +936,7 @@ int pt_create(const pt_scene_desc *scene, const pt_config *cfg_in, pt_renderer *
     if (device < 0) PT_HIP(hipGetDevice(&device));
     if (device >= ndev) return fail(PT_ERR_INVALID, "pt_create: device ordinal out of range");
     PT_HIP(hipSetDevice(device));
-    PT_HIP(scratch_init(device));  // the device is current: address of the no-alloc staging array on this GPU
+    PT_HIP(noalloc_staging_init(device));  // the device is current: address of the no-alloc staging array on this GPU
 
     pt_renderer *r = new pt_renderer();
     r->cfg = cfg;
@@ -1396,110 +1108,6 @@ int pt_render(pt_renderer *r, uint32_t n_iterations)
     return PT_OK;
 }
 
-namespace {
-struct StateHeader {
-    char magic[8];  // "PTAMDST3" ("PTAMDST2": the same header with 14 counters)
-    uint32_t width, height, max_depth, rank, world, reserved;
-    uint64_t local_iterations, paths, scene_hash;
-    float fov_y_degrees;
-    float eye[3], forward[3], up[3], right[3];
-    uint64_t counters[kCounters];  // the device counters behind pt_stats (segments, non-finite samples, ...), so that
-                                   // the statistics of a resumed render cover the whole render like `paths` does
-};
-constexpr size_t kStateHeaderV2Bytes = sizeof(StateHeader) - 2 * sizeof(uint64_t);  // version 2 ends after counters[13]
-}  // namespace
-
-int pt_save_state(pt_renderer *r, const char *path)
-{
-    PT_REQUIRE(r && path, "pt_save_state: null argument");
-    PT_USABLE(r);
-    if (r->d_rgba8) return fail(PT_ERR_STATE, "pt_save_state: not available with emulate_rgba8");
-    PT_HIP(hipSetDevice(r->device));
-    const size_t n = static_cast<size_t>(r->width) * r->height * 4;
-    std::vector<float> sum(n);
-    int rc = pt_read_sum(r, sum.data());
-    if (rc != PT_OK) return rc;
-    StateHeader h;
-    std::memset(&h, 0, sizeof(h));
-    std::memcpy(h.magic, "PTAMDST3", 8);
-    h.width = r->width;
-    h.height = r->height;
-    h.max_depth = r->cfg.max_depth;
-    h.rank = r->rank;
-    h.world = r->world;
-    h.local_iterations = r->local_iterations;
-    h.paths = r->paths;
-    h.scene_hash = r->scene_hash;
-    PT_HIP(hipMemcpy(h.counters, r->d_counters, sizeof(h.counters), hipMemcpyDeviceToHost));  // pt_read_sum has synchronised
-    h.fov_y_degrees = r->cfg.fov_y_degrees;
-    for (int k = 0; k < 3; ++k) {
-        h.eye[k] = r->cam.eye[k];
-        h.forward[k] = r->cam.forward[k];
-        h.up[k] = r->cam.up[k];
-        h.right[k] = r->cam.right[k];
-    }
-    const std::string tmp = std::string(path) + ".tmp";
-    FILE *f = std::fopen(tmp.c_str(), "wb");
-    if (!f) return fail(PT_ERR_IO, std::string("pt_save_state: cannot write ") + tmp);
-    const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(sum.data(), sizeof(float), n, f) == n;
-    const bool closed = std::fclose(f) == 0;
-    if (!ok || !closed || std::rename(tmp.c_str(), path) != 0) {
-        std::remove(tmp.c_str());
-        return fail(PT_ERR_IO, std::string("pt_save_state: writing ") + path + " failed");
-    }
-    return PT_OK;
-}
-
-int pt_load_state(pt_renderer *r, const char *path)
-{
-    PT_REQUIRE(r && path, "pt_load_state: null argument");
-    PT_USABLE(r);
-    if (r->d_rgba8) return fail(PT_ERR_STATE, "pt_load_state: not available with emulate_rgba8");
-    PT_HIP(hipSetDevice(r->device));
-    FILE *f = std::fopen(path, "rb");
-    if (!f) return fail(PT_ERR_IO, std::string("pt_load_state: cannot open ") + path);
-    StateHeader h;
-    const size_t n = static_cast<size_t>(r->width) * r->height * 4;
-    std::vector<float> sum(n);
-    std::memset(&h, 0, sizeof(h));
-    bool ok = std::fread(&h, kStateHeaderV2Bytes, 1, f) == 1;
-    if (ok && std::memcmp(h.magic, "PTAMDST1", 8) == 0) {
-        // Files of the first format carry no counters and a scene hash computed byte by byte, which this build
-        // cannot check against its own (word-wise) hash: refused by name rather than as a damaged file.
-        std::fclose(f);
-        return fail(PT_ERR_STATE, std::string("pt_load_state: ") + path +
-                                      " is a version-1 state file (PTAMDST1); this build reads versions 2 and 3 -- render again and save");
-    }
-    // version 3 carries two more counters (primary rays culled at generation, one spare); a version-2 file has
-    // none of the former, and its render had none either
-    if (ok && std::memcmp(h.magic, "PTAMDST3", 8) == 0)
-        ok = std::fread(reinterpret_cast<char *>(&h) + kStateHeaderV2Bytes, sizeof(h) - kStateHeaderV2Bytes, 1, f) == 1;
-    else
-        ok = ok && std::memcmp(h.magic, "PTAMDST2", 8) == 0;
-    const bool fits = ok && h.width == r->width && h.height == r->height;
-    ok = fits && std::fread(sum.data(), sizeof(float), n, f) == n && std::fgetc(f) == EOF;
-    std::fclose(f);
-    if (!fits) return fail(PT_ERR_STATE, std::string("pt_load_state: ") + path + " is not a state file of this image size");
-    if (!ok) return fail(PT_ERR_IO, std::string("pt_load_state: ") + path + " is truncated or has trailing data");
-    bool same = h.max_depth == r->cfg.max_depth && h.scene_hash == r->scene_hash && h.rank == r->rank &&
-                h.world == r->world && h.fov_y_degrees == r->cfg.fov_y_degrees;
-    for (int k = 0; k < 3; ++k)
-        same = same && h.eye[k] == r->cam.eye[k] && h.forward[k] == r->cam.forward[k] && h.up[k] == r->cam.up[k] &&
-               h.right[k] == r->cam.right[k];
-    if (!same)
-        return fail(PT_ERR_STATE, "pt_load_state: the file was written for another scene, camera, depth or partition");
-    const uint64_t next = h.rank + h.local_iterations * static_cast<uint64_t>(h.world);
-    if (next > 0xFFFFFFFEull) return fail(PT_ERR_STATE, "pt_load_state: iteration counter out of range");
-    int rc = reset_accumulation(r);
-    if (rc != PT_OK) return rc;
-    PT_HIP(hipMemcpyAsync(r->d_sum, sum.data(), n * sizeof(float), hipMemcpyHostToDevice, r->stream));
-    PT_HIP(hipMemcpyAsync(r->d_counters, h.counters, sizeof(h.counters), hipMemcpyHostToDevice, r->stream));
-    PT_HIP(sync_streams(r));
-    r->local_iterations = h.local_iterations;
-    r->paths = h.paths;
-    return PT_OK;
-}
-
 int pt_synchronize(pt_renderer *r)
 {
     PT_REQUIRE(r, "pt_synchronize: null argument");
@@ -1507,233 +1115,6 @@ int pt_synchronize(pt_renderer *r)
     PT_HIP(sync_streams(r));
     return PT_OK;
 }
-
-int pt_read_sum(pt_renderer *r, float *rgba)
-{
-    PT_REQUIRE(r && rgba, "pt_read_sum: null argument");
-    PT_USABLE(r);
-    PT_HIP(hipSetDevice(r->device));
-    PT_HIP(sync_streams(r));  // batches of both streams add to the sum
-    PT_HIP(hipMemcpyAsync(rgba, r->d_sum, static_cast<size_t>(r->width) * r->height * sizeof(float4), hipMemcpyDeviceToHost,
-                          r->stream));
-    PT_HIP(sync_streams(r));
-    return PT_OK;
-}
-
-int pt_read_tonemapped_noalloc(pt_renderer *r, uint8_t *rgb)
-{
-    PT_REQUIRE(r && rgb, "pt_read_tonemapped_noalloc: null argument");
-    PT_USABLE(r);
-    const size_t n = static_cast<size_t>(r->width) * r->height;
-    if (n > kNoAllocMaxPixels)
-        return fail(PT_ERR_INVALID, "pt_read_tonemapped_noalloc: " + std::to_string(r->width) + " x " + std::to_string(r->height) +
-                                        " pixels exceed the staging array (" + std::to_string(kNoAllocMaxPixels) +
-                                        " pixels, e.g. 2560 x 1440); use pt_read_tonemapped");
-    PT_HIP(hipSetDevice(r->device));
-    unsigned char *staging = (r->device >= 0 && r->device < kMaxDevices) ? g_scratch_ptr[r->device] : nullptr;
-    if (!staging) return fail(PT_ERR_STATE, "pt_read_tonemapped_noalloc: no staging array on this device");
-    PT_HIP(sync_streams(r));
-    // the kernel writes all 3 * n bytes the copy reads: nothing of an earlier call's contents is seen
-    pt::launch_tonemap(r->stream, shape_for(r, n), r->d_sum, staging, r->width, r->height);
-    PT_HIP(hipGetLastError());
-    PT_HIP(hipMemcpyAsync(rgb, staging, 3 * n, hipMemcpyDeviceToHost, r->stream));
-    PT_HIP(sync_streams(r));
-    return PT_OK;
-}
-
-int pt_read_rgba8(pt_renderer *r, uint8_t *rgba)
-{
-    PT_REQUIRE(r && rgba, "pt_read_rgba8: null argument");
-    PT_USABLE(r);
-    if (!r->d_rgba8) return fail(PT_ERR_STATE, "pt_read_rgba8: the renderer was created without emulate_rgba8");
-    PT_HIP(hipSetDevice(r->device));
-    PT_HIP(sync_streams(r));
-    PT_HIP(hipMemcpyAsync(rgba, r->d_rgba8, static_cast<size_t>(r->width) * r->height * 4, hipMemcpyDeviceToHost, r->stream));
-    PT_HIP(sync_streams(r));
-    return PT_OK;
-}
-
-int pt_read_radiance(pt_renderer *r, float *rgba)
-{
-    int rc = pt_read_sum(r, rgba);
-    if (rc != PT_OK) return rc;
-    const size_t n = static_cast<size_t>(r->width) * r->height;
-    for (size_t p = 0; p < n; ++p) {
-        const float cnt = rgba[4 * p + 3];
-        const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
-        rgba[4 * p + 0] *= inv;
-        rgba[4 * p + 1] *= inv;
-        rgba[4 * p + 2] *= inv;
-    }
-    return PT_OK;
-}
-
-int pt_read_tonemapped(pt_renderer *r, uint8_t *rgb)
-{
-    PT_REQUIRE(r && rgb, "pt_read_tonemapped: null argument");
-    PT_USABLE(r);
-    PT_HIP(hipSetDevice(r->device));
-    const size_t n = static_cast<size_t>(r->width) * r->height;
-    uint8_t *d = nullptr;
-    PT_HIP(sync_streams(r));
-    PT_HIP(hipMalloc(&d, 3 * n));
-    pt::launch_tonemap(r->stream, shape_for(r, n), r->d_sum, d, r->width, r->height);
-    hipError_t e = hipMemcpyAsync(rgb, d, 3 * n, hipMemcpyDeviceToHost, r->stream);
-    if (e == hipSuccess) e = sync_streams(r);
-    (void)hipFree(d);
-    PT_HIP(e);
-    return PT_OK;
-}
-
-}  // extern "C"
-
-namespace {
-// Primary rays of one iteration through the extend kernel, then any of: hit codes, distances, ray directions,
-// surface normals, per pixel.
-int read_primary(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, float *dirs, float *normals)
-{
-    PT_USABLE(r);
-    PT_HIP(hipSetDevice(r->device));
-    PT_HIP(sync_streams(r));
-    const size_t n = static_cast<size_t>(r->width) * r->height;
-    int32_t *d_ids = nullptr;
-    float *d_t = nullptr, *d_dirs = nullptr, *d_normals = nullptr;
-    hipError_t e = hipSuccess;
-    auto cleanup = [&]() {
-        if (d_ids) (void)hipFree(d_ids);
-        if (d_t) (void)hipFree(d_t);
-        if (d_dirs) (void)hipFree(d_dirs);
-        if (d_normals) (void)hipFree(d_normals);
-    };
-#define PT_TRY(expr)                \
-    do {                            \
-        e = (expr);                 \
-        if (e != hipSuccess) {      \
-            cleanup();              \
-            PT_HIP(e);              \
-        }                           \
-    } while (0)
-    if (ids) PT_TRY(hipMalloc(&d_ids, n * sizeof(int32_t)));
-    if (t) PT_TRY(hipMalloc(&d_t, n * sizeof(float)));
-    if (dirs) PT_TRY(hipMalloc(&d_dirs, 3 * n * sizeof(float)));
-    if (normals) PT_TRY(hipMalloc(&d_normals, 3 * n * sizeof(float)));
-    const pt::LaunchShape g = shape_for(r, n);
-    pt::launch_set_batch(r->stream, r->d_params, r->cam, iteration, 0u);
-    pt::launch_raygen(r->stream, g, r->view, r->d_params, 1, 1, r->q[0], r->d_counts, region_size_for(r, n));
-    pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, n, 0, -1), r->q[0],
-                      pt::ExtendOutput{true, r->d_hits, nullptr, false, false, r->exact_readbacks, nullptr, r->d_stack_overflow[0]},
-                      pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
-    pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(n), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids, d_t,
-                              d_dirs, &r->cam);
-    if (normals)
-        pt::launch_primary_normals(r->stream, g, static_cast<uint32_t>(n), r->view, r->q[0],
-                                   reinterpret_cast<const float2 *>(r->d_hits), d_normals, r->cam);
-    PT_TRY(hipGetLastError());
-    if (normals) PT_TRY(hipMemcpyAsync(normals, d_normals, 3 * n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
-    if (ids) PT_TRY(hipMemcpyAsync(ids, d_ids, n * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
-    if (t) PT_TRY(hipMemcpyAsync(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
-    if (dirs) PT_TRY(hipMemcpyAsync(dirs, d_dirs, 3 * n * sizeof(float), hipMemcpyDeviceToHost, r->stream));
-    PT_TRY(sync_streams(r));
-    cleanup();
-    return PT_OK;
-}
-}  // namespace
-
-extern "C" {
-
-int pt_read_hit_ids(pt_renderer *r, uint32_t iteration, int32_t *ids, float *t, float *dirs)
-{
-    PT_REQUIRE(r && (ids || t || dirs), "pt_read_hit_ids: null argument");
-    return read_primary(r, iteration, ids, t, dirs, nullptr);
-}
-
-int pt_read_hit_normals(pt_renderer *r, uint32_t iteration, float *normals)
-{
-    PT_REQUIRE(r && normals, "pt_read_hit_normals: null argument");
-    return read_primary(r, iteration, nullptr, nullptr, nullptr, normals);
-}
-
-int pt_trace_rays(pt_renderer *r, uint64_t n, const float *origins, const float *dirs, float *t, int32_t *ids)
-{
-    PT_REQUIRE(r && (n == 0 || (origins && dirs)), "pt_trace_rays: null argument");
-    PT_USABLE(r);
-    PT_HIP(hipSetDevice(r->device));
-    PT_HIP(sync_streams(r));
-    if (n == 0) return PT_OK;
-    const size_t chunk_max = r->capacity;
-    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
-    int32_t *d_ids = nullptr;
-    hipError_t e = hipSuccess;
-    auto cleanup = [&]() {
-        if (d_o) (void)hipFree(d_o);
-        if (d_d) (void)hipFree(d_d);
-        if (d_t) (void)hipFree(d_t);
-        if (d_ids) (void)hipFree(d_ids);
-    };
-    const size_t m = static_cast<size_t>(std::min<uint64_t>(n, chunk_max));
-    PT_TRY(hipMalloc(&d_o, 3 * m * sizeof(float)));
-    PT_TRY(hipMalloc(&d_d, 3 * m * sizeof(float)));
-    PT_TRY(hipMalloc(&d_t, m * sizeof(float)));
-    PT_TRY(hipMalloc(&d_ids, m * sizeof(int32_t)));
-    for (uint64_t off = 0; off < n; off += m) {
-        const size_t c = static_cast<size_t>(std::min<uint64_t>(m, n - off));
-        PT_TRY(hipMemcpyAsync(d_o, origins + 3 * off, 3 * c * sizeof(float), hipMemcpyHostToDevice, r->stream));
-        PT_TRY(hipMemcpyAsync(d_d, dirs + 3 * off, 3 * c * sizeof(float), hipMemcpyHostToDevice, r->stream));
-        const pt::LaunchShape g = shape_for(r, c);
-        pt::launch_pack_rays(r->stream, g, static_cast<uint32_t>(c), d_o, d_d, r->q[0], r->d_counts, region_size_for(r, c));
-        pt::launch_extend(r->stream, g, r->view, r->stack_entries, r->cfg.use_bvh != 0, regions_for(r, c, 0, -1), r->q[0],
-                          pt::ExtendOutput{false, r->d_hits, nullptr, false, false, r->exact_readbacks, nullptr, r->d_stack_overflow[0]},
-                          pt::TraversalCounters{nullptr, nullptr, nullptr}, r->n_nodes, r->scene_in_lds);
-        pt::launch_unpack_primary(r->stream, g, static_cast<uint32_t>(c), r->q[0], reinterpret_cast<const float2 *>(r->d_hits), d_ids,
-                                  d_t, nullptr, nullptr);
-        PT_TRY(hipGetLastError());
-        if (t) PT_TRY(hipMemcpyAsync(t + off, d_t, c * sizeof(float), hipMemcpyDeviceToHost, r->stream));
-        if (ids) PT_TRY(hipMemcpyAsync(ids + off, d_ids, c * sizeof(int32_t), hipMemcpyDeviceToHost, r->stream));
-        PT_TRY(sync_streams(r));
-    }
-    cleanup();
-    return PT_OK;
-}
-
-int pt_sample_surface(pt_renderer *r, uint64_t n, const float *materials, const float *normals, const float *wo,
-                      const float *xi, const uint32_t *seeds, float *wi_out, float *pdf_out, float *f_out,
-                      uint32_t *flags_out, uint32_t *seeds_out)
-{
-    PT_REQUIRE(r && materials && normals && wo && xi && seeds && wi_out && pdf_out && f_out && flags_out && seeds_out,
-               "pt_sample_surface: null argument");
-    PT_REQUIRE(n < (1ull << 31), "pt_sample_surface: too many records");
-    PT_HIP(hipSetDevice(r->device));
-    if (n == 0) return PT_OK;
-    // One device block: inputs then outputs, all 4-byte elements.
-    const size_t in_words = n * (8 + 3 + 3 + 2 + 2), out_words = n * (3 + 1 + 3 + 1 + 2);
-    float *d = nullptr;
-    hipError_t e = hipSuccess;
-    auto cleanup = [&]() {
-        if (d) (void)hipFree(d);
-    };
-    PT_TRY(hipMalloc(&d, (in_words + out_words) * 4));
-    float *d_mat = d, *d_nrm = d_mat + 8 * n, *d_wo = d_nrm + 3 * n, *d_xi = d_wo + 3 * n;
-    uint32_t *d_seed = reinterpret_cast<uint32_t *>(d_xi + 2 * n);
-    float *d_wi = reinterpret_cast<float *>(d_seed + 2 * n), *d_pdf = d_wi + 3 * n, *d_f = d_pdf + n;
-    uint32_t *d_flags = reinterpret_cast<uint32_t *>(d_f + 3 * n), *d_seed_out = d_flags + n;
-    PT_TRY(hipMemcpyAsync(d_mat, materials, 8 * n * 4, hipMemcpyHostToDevice, r->stream));
-    PT_TRY(hipMemcpyAsync(d_nrm, normals, 3 * n * 4, hipMemcpyHostToDevice, r->stream));
-    PT_TRY(hipMemcpyAsync(d_wo, wo, 3 * n * 4, hipMemcpyHostToDevice, r->stream));
-    PT_TRY(hipMemcpyAsync(d_xi, xi, 2 * n * 4, hipMemcpyHostToDevice, r->stream));
-    PT_TRY(hipMemcpyAsync(d_seed, seeds, 2 * n * 4, hipMemcpyHostToDevice, r->stream));
-    pt::launch_sample_surface(r->stream, shape_for(r, n), static_cast<uint32_t>(n), d_mat, d_nrm, d_wo, d_xi, d_seed, d_wi,
-                              d_pdf, d_f, d_flags, d_seed_out);
-    PT_TRY(hipGetLastError());
-    PT_TRY(hipMemcpyAsync(wi_out, d_wi, 3 * n * 4, hipMemcpyDeviceToHost, r->stream));
-    PT_TRY(hipMemcpyAsync(pdf_out, d_pdf, n * 4, hipMemcpyDeviceToHost, r->stream));
-    PT_TRY(hipMemcpyAsync(f_out, d_f, 3 * n * 4, hipMemcpyDeviceToHost, r->stream));
-    PT_TRY(hipMemcpyAsync(flags_out, d_flags, n * 4, hipMemcpyDeviceToHost, r->stream));
-    PT_TRY(hipMemcpyAsync(seeds_out, d_seed_out, 2 * n * 4, hipMemcpyDeviceToHost, r->stream));
-    PT_TRY(sync_streams(r));
-    cleanup();
-    return PT_OK;
-}
-#undef PT_TRY
 
 int pt_set_exact_readbacks(pt_renderer *r, uint32_t enabled)
 {
@@ -1749,103 +1130,6 @@ int pt_sum_device_ptr(pt_renderer *r, void **dev_ptr)
     PT_HIP(hipSetDevice(r->device));
     PT_HIP(sync_streams(r));  // the caller reads the buffer on a stream of its own
     *dev_ptr = r->d_sum;
-    return PT_OK;
-}
-
-int pt_read_bvh(pt_renderer *r, float *nodes_host, float *triangles_host)
-{
-    PT_REQUIRE(r, "pt_read_bvh: null argument");
-    PT_HIP(sync_streams(r));
-    if (nodes_host && r->n_nodes) PT_HIP(hipMemcpy(nodes_host, r->d_nodes, static_cast<size_t>(r->n_nodes) * 64, hipMemcpyDeviceToHost));
-    if (triangles_host && r->view.n_triangles)
-        PT_HIP(hipMemcpy(triangles_host, r->d_tris, static_cast<size_t>(r->view.n_triangles) * 64, hipMemcpyDeviceToHost));
-    return PT_OK;
-}
-
-int pt_bvh_inspect(const pt_scene_desc *sc, pt_bvh_info *info)
-{
-    PT_REQUIRE(sc && info, "pt_bvh_inspect: null argument");
-    const uint32_t T = sc->n_triangles;
-    PT_REQUIRE(T == 0 || (sc->vertices && sc->indices), "pt_bvh_inspect: scene arrays missing");
-    std::vector<uint32_t> ids(static_cast<size_t>(T) * 3);
-    for (uint32_t t = 0; t < T; ++t)
-        for (int k = 0; k < 3; ++k) {
-            const float f = sc->indices[4 * static_cast<size_t>(t) + k];
-            PT_REQUIRE(f >= 0.f && f < static_cast<float>(sc->n_vertices), "pt_bvh_inspect: vertex index out of range");
-            ids[3 * static_cast<size_t>(t) + k] = static_cast<uint32_t>(f);
-        }
-    const double t0 = now_ms();
-    pt::Bvh bvh;
-    if (T < (1u << 16))  // as pt_create does with the default (automatic) builder choice
-        pt::build_bvh_best_of(sc->vertices, ids.data(), T, 64, &bvh);
-    else
-        pt::build_bvh(sc->vertices, ids.data(), T, 64, &bvh);
-    std::memset(info, 0, sizeof(*info));
-    info->build_ms = now_ms() - t0;
-    info->n_triangles = T;
-    info->n_nodes = static_cast<uint32_t>(bvh.nodes.size());
-    info->depth = bvh.depth;
-    info->stack_entries = std::max<uint32_t>(4, bvh.depth + 1u);
-    info->sah_cost = bvh.sah_cost;
-
-    // Walk the tree: boxes must enclose everything below them; leaves must
-    // partition the triangle array.
-    struct Item {
-        int32_t code;
-        float lo[3], hi[3];
-        uint32_t level;
-    };
-    std::vector<Item> todo;
-    std::vector<uint8_t> seen(T, 0);
-    Item root{0, {-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}, 1};
-    todo.push_back(root);
-    uint32_t depth = 0;
-    while (!todo.empty()) {
-        Item it = todo.back();
-        todo.pop_back();
-        if (it.code >= 0) {
-            if (static_cast<size_t>(it.code) >= bvh.nodes.size()) return fail(PT_ERR_STATE, "BVH child index out of range");
-            depth = std::max(depth, it.level);
-            const pt::BvhNode &n = bvh.nodes[it.code];
-            for (int c = 0; c < 2; ++c) {
-                Item ch;
-                ch.code = n.child[c];
-                ch.level = it.level + 1;
-                for (int a = 0; a < 3; ++a) {
-                    ch.lo[a] = n.q[6 * c + a];
-                    ch.hi[a] = n.q[6 * c + 3 + a];
-                }
-                const bool empty_leaf = ch.code < 0 && ((~static_cast<uint32_t>(ch.code)) & 7u) == 0;
-                if (!empty_leaf)
-                    for (int a = 0; a < 3; ++a)
-                        if (ch.lo[a] < it.lo[a] || ch.hi[a] > it.hi[a]) return fail(PT_ERR_STATE, "BVH child box leaves its parent");
-                todo.push_back(ch);
-            }
-        } else {
-            const uint32_t code = ~static_cast<uint32_t>(it.code);
-            const uint32_t first = code >> 3, cnt = code & 7u;
-            if (cnt == 0) continue;
-            info->n_leaves++;
-            info->max_leaf_size = std::max(info->max_leaf_size, cnt);
-            if (static_cast<size_t>(first) + cnt > bvh.triangles.size()) return fail(PT_ERR_STATE, "BVH leaf range out of bounds");
-            for (uint32_t k = first; k < first + cnt; ++k) {
-                const pt::BvhTriangle &tri = bvh.triangles[k];
-                if (tri.original >= T || seen[tri.original]) return fail(PT_ERR_STATE, "triangle referenced twice or out of range");
-                seen[tri.original] = 1;
-                const float *vs[3] = {tri.v0, tri.v1, tri.v2};
-                for (const float *v : vs)
-                    for (int a = 0; a < 3; ++a)
-                        if (v[a] < it.lo[a] || v[a] > it.hi[a]) return fail(PT_ERR_STATE, "triangle vertex outside its leaf box");
-                for (int k2 = 0; k2 < 3; ++k2)
-                    for (int a = 0; a < 3; ++a)
-                        if (vs[k2][a] != sc->vertices[3 * static_cast<size_t>(ids[3 * static_cast<size_t>(tri.original) + k2]) + a])
-                            return fail(PT_ERR_STATE, "triangle record does not match the scene");
-            }
-        }
-    }
-    for (uint32_t t = 0; t < T; ++t)
-        if (!seen[t]) return fail(PT_ERR_STATE, "triangle " + std::to_string(t) + " is in no leaf");
-    if (depth != bvh.depth) return fail(PT_ERR_STATE, "reported BVH depth does not match the tree");
     return PT_OK;
 }
 
