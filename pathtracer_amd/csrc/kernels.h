@@ -154,8 +154,9 @@ struct BounceLoop {
 // Waves of k_bounces resident at once for this scene (as extend_resident_waves for the traversal kernel).
 uint32_t bounces_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds,
                                 bool overflow_buffer);
-// Whether the one launch also serves large batches best for this scene (the whole scene in LDS in small blocks;
-// measured: Box and the Anisotropic scenes +3-6 %, scenes in one large block per CU -8 %, trees in memory -5 %).
+// Whether the one launch also serves large batches best for this scene (the whole scene in LDS; measured: Box and
+// the Anisotropic scenes, in small blocks, +3-6 %; the Transmission scenes, one large block per CU, +1.5 %; Veggie,
+// one large block with most triangles in memory, -9 %; trees in memory -5 %).
 bool bounces_suit_any_batch(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds, bool overflow_buffer);
 void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, const BounceLoop &loop,
                     const BatchParams *params, uint32_t n_nodes, bool scene_in_lds, int *stack_overflow, uint32_t it_stride,

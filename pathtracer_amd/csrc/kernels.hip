@@ -2162,7 +2162,9 @@ uint32_t bounces_resident_waves(uint32_t n_cus, const SceneView &scene, uint32_t
 bool bounces_suit_any_batch(const SceneView &scene, uint32_t stack_entries, uint32_t n_nodes, bool scene_in_lds, bool overflow_buffer)
 {
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, overflow_buffer);
-    return plan.block == 256 && (plan.mode == 2 || plan.mode == 3);
+    // (one large block per CU: only with every triangle in LDS -- a block whose leaf tests go to memory loses more
+    // without a second batch's kernels beside it than it gains from having no launch tails)
+    return (plan.block == 256 && (plan.mode == 2 || plan.mode == 3)) || (plan.block == 1024 && plan.mode == 2);
 }
 
 void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, const BounceLoop &loop,
