@@ -134,7 +134,7 @@ typedef struct {
     uint32_t bvh_builder;     /* the builder that made the tree: 0 host, 1 device */
     uint32_t reserved;
     /* Batches whose bounces all ran in one launch (small batches, and every batch of a scene that lives on
-     * chip in small blocks): duration and count of those launches (profile bit 0); ms_extend / ms_shade then
+     * chip with all its triangles): duration and count of those launches (profile bit 0); ms_extend / ms_shade then
      * cover only the batches that were launched kernel by kernel. */
     double ms_bounces;
     uint64_t launches_bounces;

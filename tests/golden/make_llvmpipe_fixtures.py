@@ -9,6 +9,7 @@ reference rendered); no reference source is stored.
   python tests/golden/make_llvmpipe_fixtures.py timing   # llvmpipe throughput table
   python tests/golden/make_llvmpipe_fixtures.py ids_large  # hit buffers at benchmark sizes, a moved camera (minutes)
   python tests/golden/make_llvmpipe_fixtures.py post     # what post.frag draws from a float image
+  python tests/golden/make_llvmpipe_fixtures.py image_filtered_4k  # Veggie at 3840x2160, kept as 16x16 block means (~25 min)
 """
 import glob
 import json
@@ -84,6 +85,21 @@ def image_fixture(name, w, h, spp, depth):
           "%.1fs" % (time.time() - t0), os.path.getsize(path), flush=True)
 
 
+def filtered_image_fixture(name, w, h, spp, depth, block=16):
+    """The same image at a size whose pixels would not fit in the repository: kept as the means of its block x block
+    pixel blocks (what the filtered relMSE and the channel means of the image gate are computed from), float32."""
+    a, c = scene_and_cam(name, w, h)
+    t0 = time.time()
+    img, secs = rr.run(a, c, w, h, "float0", spp, depth)
+    rgb = img[..., :3].astype(np.float64)
+    assert h % block == 0 and w % block == 0
+    means = rgb.reshape(h // block, block, w // block, block, 3).mean(axis=(1, 3)).astype(np.float32)
+    path = os.path.join(OUT, f"image_{name}_{w}x{h}_spp{spp}_depth{depth}_block{block}.npz")
+    np.savez_compressed(path, block_means=means, block=np.int32(block), channel_means=rgb.mean(axis=(0, 1)),
+                        spp=np.int32(spp), depth=np.int32(depth), llvmpipe_seconds=np.float64(secs))
+    print(name, w, h, spp, depth, "mean", rgb.mean(axis=(0, 1)), "%.1fs" % (time.time() - t0), os.path.getsize(path), flush=True)
+
+
 def main():
     what =sys.argv[1] if len(sys.argv) > 1 else "ids"
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(HERE, "scenes", "*.npz")))
@@ -131,6 +147,8 @@ def main():
         # float images at the benchmark size and depth (iterations 0..15): Box ~1 min, Veggie ~6 min on 8 cores
         for n in sys.argv[2:] or ("Box", "Veggie"):
             image_fixture(n, 1920, 1080, 16, 8)
+    elif what == "image_filtered_4k":
+        filtered_image_fixture("Veggie", 3840, 2160, 16, 8)
     elif what == "image_no_usemtl":
         # cube.obj has no usemtl: its faces carry material id 0xFFFFFFFF (scene.h:133), and what such a surface
         # scatters is whatever the driver returns for the out-of-range buffer-texture fetches of frag:105-126

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import LLVMPIPE, default_camera_axes, hit_fixture, scene_arrays
+from conftest import LLVMPIPE, box_filter, default_camera_axes, hit_fixture, rel_mse, scene_arrays
 
 pytestmark = pytest.mark.gpu
 
@@ -117,6 +117,38 @@ def test_veggie_at_3840x2160(pt):
     assert 2.0 < st["segments"] / st["paths"] < 4.5
     mean = a[..., :3].mean(axis=(0, 1)) / 10
     assert 0.02 < mean.min() and mean.max() < 0.15
+
+
+def test_veggie_image_against_reference_at_3840x2160(pt):
+    """The image of the 4K configuration against the reference shader's at that size: Veggie, 3840x2160, depth 8,
+    iterations 0..15 (llvmpipe takes 25 minutes for them on 8 cores).  A 4K float image does not fit in the
+    repository, so the fixture keeps the means of its 16x16 pixel blocks -- what the filtered part of the image
+    gate is computed from anyway: filtered relMSE (mean (I-R)^2/(R^2+0.01)) <= 2x the floor (two independent
+    renders of our own, iterations 0..15 against 16..31) and <= 3 x 2e-4 x 256/spp, channel means within 1 %.
+    Both sides draw the same random numbers and make the same intersections: the observed distance is orders of
+    magnitude below the floor."""
+    w, h, spp, depth = 3840, 2160, 16, 8
+    path = os.path.join(LLVMPIPE, f"image_Veggie_{w}x{h}_spp{spp}_depth{depth}_block16.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    z = np.load(path)
+    ref_f = z["block_means"].astype(np.float64)
+    r = pt.Renderer(_scene(pt, "Veggie"), pt.Camera(resolution=(w, h)), max_depth=depth)
+    r.draw(spp)
+    s1 = r.read_sum()
+    r.draw(spp)
+    s2 = r.read_sum() - s1
+    r.close()
+    assert np.all(s1[..., 3] == spp)
+    a_f, b_f = box_filter(s1[..., :3] / float(spp)), box_filter(s2[..., :3] / float(spp))
+    assert a_f.shape == ref_f.shape
+    floor_f, got_f = rel_mse(b_f, a_f), rel_mse(a_f, ref_f)
+    print(f"Veggie 4K {spp} spp: 16x16-filtered relMSE {got_f:.4g} (floor {floor_f:.4g})")
+    assert got_f <= 2.0 * floor_f + 1e-5, (got_f, floor_f)
+    assert got_f <= 3.0 * 2.0e-4 * 256.0 / spp
+    assert got_f <= 1e-2 * floor_f, (got_f, floor_f)
+    ma, mr = a_f.mean(axis=(0, 1)), z["channel_means"]
+    assert np.all(np.abs(ma - mr) <= 0.01 * mr), (ma, mr)
 
 
 def test_ten_million_triangle_scene_rendered_at_3840x2160(pt, ob):

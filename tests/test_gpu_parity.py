@@ -377,7 +377,7 @@ def _reference_image(name, w, h, spp, depth):
 def test_image_against_reference_at_1920x1080(pt, name):
     """The benchmark configurations themselves (the two headline scenes and the four scenes of the transmission
     and anisotropy configurations): 1920x1080, depth 8, through the renderer's default path (all bounces of a
-    batch in one launch for Box and the Anisotropic scenes, separate kernels on two streams for the others),
+    batch in one launch, except Veggie: separate kernels on two streams),
     against the reference shader's float image of the same iterations 0..15 (llvmpipe takes half a minute to
     six minutes per scene at 16 spp).  Tolerances (relMSE = mean (I-R)^2/(R^2+0.01)), the noise floor being the relMSE between
     two independent renders of our own (iterations 0..15 against 16..31):
