@@ -56,7 +56,7 @@ SHADE_READ_PER_HIT = 16 + 48           # hit record + path state
 SHADE_WRITE_PER_SURVIVOR = 48 + 4      # compacted state of a surviving path + its light distance
 RAYGEN_BYTES_PER_RAY = 48 + 4          # the three lanes of a primary ray that is enqueued + its light distance (rays of pixels
                                        # outside the scene's window are never made: pt_stats.primary_rays_culled)
-SAMPLE_BYTES = 16                      # one radiance sample per path (read by accumulate)
+SAMPLE_BYTES = 16                      # one radiance sample per path whose primary ray was made (read by accumulate)
 
 
 def parse_args():
@@ -386,7 +386,8 @@ def main():
                 "raygen": {"ms_total": p["ms_raygen"], "launches": p["launches_raygen"],
                            "algorithmic_bytes": RAYGEN_BYTES_PER_RAY * primaries if p["launches_raygen"] else 0},
                 "accumulate": {"ms_total": p["ms_accumulate"], "launches": p["launches_accumulate"],
-                               "algorithmic_bytes": SAMPLE_BYTES * p["paths"] + 32 * n_pixels * p["launches_accumulate"]},
+                               # (the samples of pixels whose primary rays were never made are not read)
+                               "algorithmic_bytes": SAMPLE_BYTES * primaries + 32 * n_pixels * p["launches_accumulate"]},
             }
             for k in table.values():
                 k["avg_launch_ms"] = k["ms_total"] / max(1, k["launches"])

@@ -176,7 +176,8 @@ void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, floa
                        uint32_t pitch, unsigned long long *segments_total,
                        unsigned long long *shade_totals /* [0] surface hits shaded, [1] 64-lane batches formed */,
                        unsigned long long *nan_counter, unsigned long long *culled_total /* primary rays not enqueued (counts row 2*n_rows+1) */,
-                       uint8_t *rgba8 /* may be null */, const BatchParams *params, uint32_t it_stride);
+                       uint8_t *rgba8 /* may be null */, const BatchParams *params, uint32_t it_stride,
+                       bool culled /* the batch's ray generation left out the pixels outside the camera's window: their samples are not read */);
 
 // hits -> int32 hit codes / t / directions in pixel order for one iteration.
 // cam: the camera whose raygen made the rays (its slot -> pixel mapping orders the output by pixel); null: rays

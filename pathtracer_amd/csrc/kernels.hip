@@ -1646,7 +1646,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
                                                         unsigned long long *__restrict__ nan_counter,
                                                         unsigned long long *__restrict__ culled_total,
                                                         uint8_t *__restrict__ rgba8, const BatchParams *__restrict__ bp,
-                                                        uint32_t it_stride)
+                                                        uint32_t it_stride, uint32_t culled)
 {
     const uint32_t it_first = bp->it_first, sample_tag = bp->sample_tag;
     {
@@ -1686,8 +1686,21 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
         if ((threadIdx.x & 63u) == 0 && culled != 0) atomicAdd(culled_total, culled);
     }
     unsigned long long dropped = 0;
+    // culled: ray generation made no ray for the pixels outside the camera's window (raygen_regions), so none of
+    // their sample slots was written in this batch: they get their count and nothing is read for them
+    const uint32_t width = bp->cam.width, cx0 = bp->cam.cull_x0, cx1 = bp->cam.cull_x1, cy0 = bp->cam.cull_y0, cy1 = bp->cam.cull_y1;
+    const FastDiv div_width = bp->cam.div_width;
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < n_pixels; p += gridDim.x * kBlock) {
         float4 acc = sum[p];
+        if (culled) {
+            uint32_t x;
+            const uint32_t y = div_by(p, width, div_width, x);
+            if (x < cx0 || x > cx1 || y < cy0 || y > cy1) {
+                for (uint32_t k = 0; k < n_iterations; ++k) acc.w += 1.f;  // (one by one, like the samples that are read)
+                sum[p] = acc;
+                continue;
+            }
+        }
         uchar4 tex = rgba8 ? reinterpret_cast<uchar4 *>(rgba8)[p] : make_uchar4(0, 0, 0, 0);
         for (uint32_t k = 0; k < n_iterations; ++k) {
             float4 s = samples[static_cast<size_t>(k) * n_pixels + p];
@@ -2198,11 +2211,11 @@ void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, floa
                        uint32_t n_iterations, const uint32_t *counts, uint32_t n_rows, uint32_t n_regions,
                        uint32_t pitch, unsigned long long *segments_total, unsigned long long *shade_totals,
                        unsigned long long *nan_counter, unsigned long long *culled_total, uint8_t *rgba8, const BatchParams *params,
-                       uint32_t it_stride)
+                       uint32_t it_stride, bool culled)
 {
     hipLaunchKernelGGL(k_accumulate, dim3(g.blocks), dim3(kBlock), 0, s, samples, sum, n_pixels, n_iterations, counts,
                        n_rows, n_regions, pitch, segments_total, shade_totals, nan_counter, culled_total,
-                       rgba8, params, it_stride);
+                       rgba8, params, it_stride, culled ? 1u : 0u);
 }
 
 void launch_unpack_primary(hipStream_t s, LaunchShape g, uint32_t n, PathQueue q, const float2 *hits, int32_t *ids,

@@ -502,6 +502,15 @@ void drain_events(pt_renderer *r)
     r->timed.clear();
 }
 
+// Whether the batches' ray generation leaves out the pixels outside the camera's window.  (Not with the
+// exact-samples pass: a ray that misses the scene may still be the reference's hit at t = inf; the scan kernel
+// has no window either.)
+bool primary_rays_culled(const pt_renderer *r)
+{
+    const bool exact_samples = r->cfg.emulate_rgba8 || (r->cfg.profile & 4u);
+    return !exact_samples && r->cfg.use_bvh != 0;
+}
+
 // The launches of one batch up to (not including) its accumulate kernel: raygen, then extend / shade per bounce.
 // Everything that differs from batch to batch is read from the lane's BatchParams block, so for a given lane and
 // batch size these launches are always the same.
@@ -532,7 +541,7 @@ void enqueue_bounces(pt_renderer *r, uint32_t lane, uint32_t kb, hipStream_t st)
         // (with the exact-samples pass a ray that misses the scene may still be a hit at t = inf: nothing is culled)
         Timed t(r, 0, st);
         pt::launch_raygen_regions(st, g, r->view, bp, r->world, kb, q[0], regions_for(r, n_paths, 0, 0, d_counts),
-                                  d_counts + static_cast<size_t>(2 * depth + 1) * r->region_pitch, !exact_samples && r->cfg.use_bvh != 0);
+                                  d_counts + static_cast<size_t>(2 * depth + 1) * r->region_pitch, primary_rays_culled(r));
     }
     for (uint32_t b = 0; b < depth; ++b) {
         const pt::PathQueue &in = q[b & 1], &out = q[(b + 1) & 1];
@@ -587,11 +596,13 @@ int render_batch(pt_renderer *r, uint64_t first_k, uint32_t kb)
     {
         // sum += samples in batch order: wait for the other set's accumulate, which belongs to the batch before
         if (r->ev_accum_set[lane ^ 1u]) PT_HIP(hipStreamWaitEvent(st, r->ev_accum[lane ^ 1u], 0));
+        static const bool accumulate_reads_all = pt::tuning_env("PT_ACCUMULATE_ALL") != nullptr;  // tuning experiments only
         {
             Timed t(r, 3, st);
             pt::launch_accumulate(st, shape_for(r, n_pixels), d_samples, r->d_sum, static_cast<uint32_t>(n_pixels), kb, d_counts,
                                   depth, regions_for(r, n_paths, 0, -1, d_counts).n_regions, r->region_pitch, r->d_counters,
-                                  r->d_counters + 12, r->d_counters + 1, r->d_counters + 14, r->d_rgba8, r->d_params + lane, r->world);
+                                  r->d_counters + 12, r->d_counters + 1, r->d_counters + 14, r->d_rgba8, r->d_params + lane, r->world,
+                                  primary_rays_culled(r) && !accumulate_reads_all);
         }
         if (r->two_lanes) {
             PT_HIP(hipEventRecord(r->ev_accum[lane], st));
