@@ -1637,6 +1637,11 @@ __device__ __forceinline__ unsigned char unorm8(float x)
 
 // sum[pixel] += each of the batch's samples of that pixel, in iteration order
 // (so the image does not depend on how many iterations share a batch).
+// RGBA8: also keep the reference's 8-bit running average (a variant of its own, so that the usual one stays within
+// 32 registers: that is what five resident waves of the kernel that runs all bounces of a batch, 96 registers each,
+// leave free on a SIMD -- this kernel's blocks then start beside them instead of waiting for one of them to retire,
+// and the other batch's next launch waits for this kernel).
+template <bool RGBA8>
 __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict__ samples, float4 *__restrict__ sum,
                                                         uint32_t n_pixels, uint32_t n_iterations,
                                                         const uint32_t *__restrict__ counts, uint32_t n_rows,
@@ -1701,7 +1706,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
                 continue;
             }
         }
-        uchar4 tex = rgba8 ? reinterpret_cast<uchar4 *>(rgba8)[p] : make_uchar4(0, 0, 0, 0);
+        uchar4 tex = RGBA8 ? reinterpret_cast<uchar4 *>(rgba8)[p] : make_uchar4(0, 0, 0, 0);
         for (uint32_t k = 0; k < n_iterations; ++k) {
             float4 s = samples[static_cast<size_t>(k) * n_pixels + p];
             if (__float_as_uint(s.w) != sample_tag) s = make_float4(0.f, 0.f, 0.f, 0.f);  // not written in this batch: the path escaped
@@ -1713,7 +1718,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
                 ++dropped;  // the float image counts a non-finite sample as zero
             }
             acc.w += 1.f;
-            if (rgba8) {
+            if (RGBA8) {
                 // frag:900-904 on an 8-bit UNORM texel: col = (accumCol * it + passCol) / (it + 1), then the
                 // store clamps to [0,1] and rounds to 8 bits (NaN becomes 0).
                 const float fi = static_cast<float>(it_first + k * it_stride), fi1 = static_cast<float>(it_first + k * it_stride + 1u);
@@ -1727,7 +1732,7 @@ __global__ void __launch_bounds__(kBlock) k_accumulate(const float4 *__restrict_
             }
         }
         sum[p] = acc;
-        if (rgba8) reinterpret_cast<uchar4 *>(rgba8)[p] = tex;
+        if (RGBA8) reinterpret_cast<uchar4 *>(rgba8)[p] = tex;
     }
     for (int off = 32; off > 0; off >>= 1) dropped += __shfl_down(dropped, off);
     if ((threadIdx.x & 63u) == 0 && dropped != 0) atomicAdd(nan_counter, dropped);
@@ -2213,8 +2218,8 @@ void launch_accumulate(hipStream_t s, LaunchShape g, const float4 *samples, floa
                        unsigned long long *nan_counter, unsigned long long *culled_total, uint8_t *rgba8, const BatchParams *params,
                        uint32_t it_stride, bool culled)
 {
-    hipLaunchKernelGGL(k_accumulate, dim3(g.blocks), dim3(kBlock), 0, s, samples, sum, n_pixels, n_iterations, counts,
-                       n_rows, n_regions, pitch, segments_total, shade_totals, nan_counter, culled_total,
+    hipLaunchKernelGGL(rgba8 ? k_accumulate<true> : k_accumulate<false>, dim3(g.blocks), dim3(kBlock), 0, s, samples, sum, n_pixels,
+                       n_iterations, counts, n_rows, n_regions, pitch, segments_total, shade_totals, nan_counter, culled_total,
                        rgba8, params, it_stride, culled ? 1u : 0u);
 }
 
