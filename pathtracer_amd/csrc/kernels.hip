@@ -1939,13 +1939,13 @@ void launch_raygen_regions(hipStream_t s, LaunchShape g, const SceneView &scene,
 
 namespace {
 // Dynamic LDS of the traversal kernel: as much of the scene as the block may hold, then the per-lane stacks.
-// Four blocks of 256 threads per CU with 40 KB each, or one block of 1024 threads with 160 KB (16 waves per CU
-// either way; measured: 3 waves per SIMD is 27 % slower).  In order of preference: all nodes and triangles
-// (mode 2) in small blocks, the same in a large block, all nodes (mode 3) in small blocks, in a large block,
-// else small blocks with the top of the tree (1) or nothing (0).
+// Four blocks of 256 threads per CU with 40 KB each, two blocks of 512 with 80 KB each, or one block of 1024
+// threads with 160 KB (16 waves per CU in each case; measured: 3 waves per SIMD is 27 % slower).  In order of
+// preference: all nodes and triangles (mode 2) in the smallest blocks that hold them, all nodes (mode 3) in small
+// blocks, in a large block, else small blocks with the top of the tree (1) or nothing (0).
 constexpr size_t kLdsPerCu = 160 * 1024;
 struct LdsPlan {
-    int block;  // threads per block: 256 or 1024
+    int block;  // threads per block: 256, 512 or 1024
     int mode;
     uint32_t lds_stack_entries;  // entries of every lane's stack kept in LDS (the rest: the launch's overflow buffer)
     uint32_t n_lds_nodes;
@@ -1960,7 +1960,7 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
         return static_cast<size_t>(e ? std::atoi(e) : 40) * 1024;
     }();
     static const int only_block = [] {
-        const char *e = pt::tuning_env("PT_EXT_BLOCK");  // tuning experiments only: 256 or 1024
+        const char *e = pt::tuning_env("PT_EXT_BLOCK");  // tuning experiments only: 256, 512 or 1024
         return e ? std::atoi(e) : 0;
     }();
     constexpr size_t budget_large = kLdsPerCu;
@@ -1970,9 +1970,13 @@ LdsPlan plan_lds(const SceneView &scene, uint32_t stack_entries, uint32_t n_node
     // banks (80 bytes) before packed ones (64).  With all nodes in LDS a node takes 112 bytes (the kernel's own
     // layout of them); inner-child codes are LDS addresses there, which keeps the nodes below 2^31 by far.
     for (int mode : {2, 3})
-        for (int block : {256, 1024}) {
+        for (int block : {256, 512, 1024}) {
             if (only_block && block != only_block) continue;
-            const size_t budget = block == 256 ? budget_small : budget_large;
+            // (two blocks of 512 threads per CU, for scenes that fit twice with all their triangles: the same 16 waves
+            // per CU as one block of 1024, but blocks retire and are replaced at half the granularity, so the tails of
+            // one batch's launch and the head of the next overlap better -- Box_Transmission +3.8 %)
+            if (block == 512 && mode != 2) continue;
+            const size_t budget = block == 256 ? budget_small : (block == 512 ? budget_large / 2 : budget_large);
             for (uint32_t stride : {5u, 4u}) {
                 const size_t bytes = stack_bytes(block) + static_cast<size_t>(n_nodes) * 112 +
                                      (mode == 2 ? static_cast<size_t>(scene.n_triangles) * 16 * stride : 0);
@@ -2067,6 +2071,7 @@ ExtendKernel extend_kernel_for(bool counting, bool exact, bool render, bool use_
 }
 ExtendKernel extend_kernel(const LdsPlan &plan, bool counting, bool exact, bool render, bool use_lt)
 {
+    if (plan.block == 512) return extend_kernel_for<512, 2>(counting, exact, render, use_lt);
     if (plan.block == 1024) {  // large blocks exist for the modes that keep something in LDS
         if (plan.mode == 2) return extend_kernel_for<1024, 2>(counting, exact, render, use_lt);
         if (plan.mode == 3) return extend_kernel_for<1024, 3>(counting, exact, render, use_lt);
@@ -2155,6 +2160,7 @@ BouncesKernel bounces_kernel_for(bool use_lt)
 }
 BouncesKernel bounces_kernel(const LdsPlan &plan, bool use_lt)
 {
+    if (plan.block == 512) return bounces_kernel_for<512, 2>(use_lt);
     if (plan.block == 1024) {
         if (plan.mode == 2) return bounces_kernel_for<1024, 2>(use_lt);
         if (plan.mode == 3) return bounces_kernel_for<1024, 3>(use_lt);
@@ -2182,7 +2188,7 @@ bool bounces_suit_any_batch(const SceneView &scene, uint32_t stack_entries, uint
     const LdsPlan plan = plan_lds(scene, stack_entries, n_nodes, scene_in_lds, overflow_buffer);
     // (one large block per CU: only with every triangle in LDS -- a block whose leaf tests go to memory loses more
     // without a second batch's kernels beside it than it gains from having no launch tails)
-    return (plan.block == 256 && (plan.mode == 2 || plan.mode == 3)) || (plan.block == 1024 && plan.mode == 2);
+    return (plan.block == 256 && (plan.mode == 2 || plan.mode == 3)) || (plan.block >= 512 && plan.mode == 2);
 }
 
 void launch_bounces(hipStream_t s, LaunchShape g, const SceneView &scene, uint32_t stack_entries, const BounceLoop &loop,
