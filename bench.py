@@ -70,7 +70,9 @@ def parse_args():
     p.add_argument("--depth", type=int, default=8)
     p.add_argument("--spp-per-step", type=int, default=512,
                    help="samples per pixel one step renders on every rank (weak scaling)")
-    p.add_argument("--batch-spp", type=int, default=32, help="samples per pixel in flight together (pt_config.iterations_per_batch)")
+    p.add_argument("--batch-spp", type=int, default=0,
+                   help="samples per pixel in flight together (pt_config.iterations_per_batch); 0 = the renderer's own choice "
+                        "for the scene and image size, reported in config.workload")
     p.add_argument("--batch-streams", type=int, default=2, choices=(1, 2),
                    help="2: two batches in flight on two streams (the product default); 1: one batch at a time")
     p.add_argument("--total-spp", type=int, default=0,
@@ -182,20 +184,21 @@ def timed_run(pt, dist, args, scene_name, rank, world, device, reducer):
     return dt, r
 
 
-def kernel_profile(pt, args, scene_name, device, rank, world, batch_streams=2, counters=True, separate_launches=False):
+def kernel_profile(pt, args, scene_name, device, rank, world, batch_spp, batch_streams=2, counters=True, separate_launches=False):
     """Same workload with every launch bracketed by HIP events on the stream it is
     launched on (pt_config.profile).  batch_streams = 2: as in the timed run, the
     kernels of two batches overlap and a launch's duration includes what it shares
     with the other batch; 1: every kernel alone on the GPU.  separate_launches: one
     launch per kernel and bounce also where the renderer would run all bounces of a
-    batch in one launch (profile bit 4), for the per-kernel breakdown."""
+    batch in one launch (profile bit 4), for the per-kernel breakdown.  batch_spp: the batch size of the timed run
+    (the profiling switches would change the renderer's own choice)."""
     cam = pt.Camera(resolution=(args.width, args.height))
     r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
-                    iterations_per_batch=args.batch_spp, profile=1 | (16 if separate_launches else 0) | (32 if args.wide_tree else 0),
+                    iterations_per_batch=batch_spp, profile=1 | (16 if separate_launches else 0) | (32 if args.wide_tree else 0),
                     batch_streams=batch_streams)
     r.set_partition(rank, world)
     spp = max(1, spp_of_step(args, rank, world))
-    r.draw(min(spp, args.batch_spp))  # warm
+    r.draw(min(spp, batch_spp))  # warm
     r.synchronize()
     r.reset()
     steps = max(1, min(args.steps, 4))
@@ -208,9 +211,9 @@ def kernel_profile(pt, args, scene_name, device, rank, world, batch_streams=2, c
     # Work counters (BVH nodes fetched, triangle tests) come from a separate
     # instrumented pass so that they do not slow the timed kernels down.
     r = pt.Renderer(load_scene(pt, scene_name), cam, max_depth=args.depth, device=device,
-                    iterations_per_batch=args.batch_spp, profile=2 | (32 if args.wide_tree else 0))
+                    iterations_per_batch=batch_spp, profile=2 | (32 if args.wide_tree else 0))
     r.set_partition(rank, world)
-    r.draw(min(spp, args.batch_spp))
+    r.draw(min(spp, batch_spp))
     c = r.stats()
     r.close()
     scale = st["segments"] / max(1, c["segments"])
@@ -354,14 +357,15 @@ def main():
         gates["image_finite"] = bool(np.isfinite(s).all())
     r.close()
 
-    prof = kernel_profile(pt, args, args.scene, device, rank, world, batch_streams=args.batch_streams)
+    batch_spp = st["iterations_per_batch"]  # what the timed renderer used (its own choice unless --batch-spp)
+    prof = kernel_profile(pt, args, args.scene, device, rank, world, batch_spp, batch_streams=args.batch_streams)
     # the same kernels one at a time (one stream): what a launch takes when it has the GPU to itself
-    prof_alone = None if args.no_alone else kernel_profile(pt, args, args.scene, device, rank, world, batch_streams=1,
+    prof_alone = None if args.no_alone else kernel_profile(pt, args, args.scene, device, rank, world, batch_spp, batch_streams=1,
                                                             counters=False)
     # where the timed run puts all bounces of a batch in one launch: the same work kernel by kernel, for the breakdown
     prof_sep = None
     if prof["launches_bounces"] and not args.no_alone:
-        prof_sep = kernel_profile(pt, args, args.scene, device, rank, world, batch_streams=1, counters=False,
+        prof_sep = kernel_profile(pt, args, args.scene, device, rank, world, batch_spp, batch_streams=1, counters=False,
                                   separate_launches=True)
     out = None
     if rank == 0:
@@ -485,7 +489,7 @@ def main():
             "config": {"workload": f"{scene_label} {args.width}x{args.height}, max depth {args.depth}, "
                                    + (f"{args.total_spp} spp per step in total over {world} GPU(s)" if args.total_spp else
                                       f"{args.spp_per_step} spp per step per GPU")
-                                   + f", batches of {args.batch_spp} spp, default camera and light",
+                                   + f", batches of {batch_spp} spp, default camera and light",
                        "paths_per_step": n_pixels * spp_all_ranks, "parallelism": f"sample-partition x{world}",
                        "reduce": reducer.kind if reducer else None,
                        "reduce_libraries": getattr(reducer, "libraries", None)},

@@ -62,7 +62,8 @@ typedef struct {
     int32_t device;                /* HIP device ordinal; -1 = current device           */
     uint32_t use_bvh;              /* 1 = SAH BVH traversal; 0 = linear scan in the
                                       reference's triangle order (frag:391-416)         */
-    uint32_t iterations_per_batch; /* samples per pixel in flight at once; 0 = auto     */
+    uint32_t iterations_per_batch; /* samples per pixel in flight at once; 0 = auto (about 64 M or 128 M paths,
+                                      see pt_stats.iterations_per_batch) */
     uint32_t profile;              /* bit 0: time every launch with HIP events; bit 1:
                                       count BVH nodes / triangle tests (both slower);
                                       bit 2: produce the reference's non-finite samples one
@@ -132,7 +133,8 @@ typedef struct {
      * the 64-lane batches they were processed in (fill = hits / (64 * batches)). */
     uint64_t hits_shaded, shade_batches;
     uint32_t bvh_builder;     /* the builder that made the tree: 0 host, 1 device */
-    uint32_t reserved;
+    uint32_t iterations_per_batch; /* samples per pixel that share a batch (pt_config.iterations_per_batch, or what
+                                    * the renderer chose for 0 = auto at this image size and for this scene) */
     /* Batches whose bounces all ran in one launch (small batches, and every batch of a scene that lives on
      * chip with all its triangles): duration and count of those launches (profile bit 0); ms_extend / ms_shade then
      * cover only the batches that were launched kernel by kernel. */

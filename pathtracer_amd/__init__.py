@@ -112,7 +112,7 @@ class Stats(C.Structure):
         ("hits_shaded", C.c_uint64),
         ("shade_batches", C.c_uint64),
         ("bvh_builder", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("iterations_per_batch", C.c_uint32),
         ("ms_bounces", C.c_double),
         ("launches_bounces", C.c_uint64),
         ("primary_rays_culled", C.c_uint64),

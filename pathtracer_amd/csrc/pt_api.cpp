@@ -136,17 +136,22 @@ uint32_t gcd_u32(uint32_t a, uint32_t b)
     return a;
 }
 
+bool bounces_in_one_launch(const pt_renderer *r, size_t n_paths);
+
 // Samples per pixel that share a batch at this image size; 0 when the image has more pixels than path slots
-// can be numbered (32 bits).
+// can be numbered (32 bits).  (r->bounces_any_size is known: alloc_paths sets it first.)
 uint32_t batch_iterations_for(const pt_renderer *r, uint32_t width, uint32_t height)
 {
     const size_t n_pixels = static_cast<size_t>(width) * height;
     uint32_t k = r->cfg.iterations_per_batch;
     if (k == 0) {
         // Enough paths in flight to keep 256 CUs busy after compaction has thinned the queue, and launches
-        // long enough that their ends weigh little: about 64M slots (8.6 GB of queues per set of
-        // buffers), at most 32 samples per pixel.
-        k = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(32, (size_t(64) << 20) / std::max<size_t>(1, n_pixels))));
+        // long enough that their ends weigh little: about 64 M slots (8.6 GB of queues per set of buffers) when
+        // all bounces of a batch go in one launch, twice that when every bounce is a launch of its own, each
+        // ending in a tail of thinning waves (measured with both: Veggie +1-3 % at 1080p, +5 % at 3840x2160; Box,
+        // one launch, -2 %).  At most 128 samples per pixel (Box at 512 x 512: +3 % over 32).
+        const size_t target = bounces_in_one_launch(r, ~size_t(0)) ? (size_t(64) << 20) : (size_t(128) << 20);
+        k = static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(128, target / std::max<size_t>(1, n_pixels))));
     }
     while (k > 1 && n_pixels * k >= (size_t(1) << 31)) --k;
     return n_pixels * k >= (size_t(1) << 31) ? 0u : k;
@@ -173,6 +178,8 @@ bool bounces_in_one_launch(const pt_renderer *r, size_t n_paths);
 
 int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
 {
+    r->bounces_any_size = r->cfg.use_bvh && pt::bounces_suit_any_batch(r->view, r->stack_entries, r->n_nodes, r->scene_in_lds,
+                                                                     r->d_stack_overflow[0] != nullptr);
     const uint32_t k = batch_iterations_for(r, width, height);
     if (k == 0) return fail(PT_ERR_INVALID, "resolution too large");  // nothing has been freed yet
     free_paths(r);
@@ -198,8 +205,6 @@ int alloc_paths(pt_renderer *r, uint32_t width, uint32_t height)
         r->bounces_waves = r->cfg.use_bvh ? pt::bounces_resident_waves(r->n_cus, r->view, r->stack_entries, r->n_nodes, r->scene_in_lds,
                                                                        r->d_stack_overflow[0] != nullptr)
                                           : r->extend_waves;
-        r->bounces_any_size = r->cfg.use_bvh && pt::bounces_suit_any_batch(r->view, r->stack_entries, r->n_nodes, r->scene_in_lds,
-                                                                         r->d_stack_overflow[0] != nullptr);
         const uint32_t waves = bounces_in_one_launch(r, r->capacity) ? r->bounces_waves : r->extend_waves;
         const size_t target = region_target_slots();
         size_t m = std::max<size_t>(1, (r->capacity + size_t(waves) * (target / 2)) / (size_t(waves) * target));
@@ -1180,7 +1185,7 @@ int pt_get_stats(pt_renderer *r, pt_stats *s)
     s->hits_shaded = c[12];
     s->shade_batches = c[13];
     s->bvh_builder = r->bvh_builder;
-    s->reserved = 0;
+    s->iterations_per_batch = r->batch_iterations;
     s->primary_rays_culled = c[14];
     s->unlit_last_rays_skipped = c[15];
     s->segments += c[15];  // (they are segments of their paths all the same)

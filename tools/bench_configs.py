@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 import pathtracer_amd as pt  # noqa: E402
 
 CONFIGS = [
-    # name, scene, lattice n, width, height, depth, spp per batch, batches
+    # name, scene, lattice n, width, height, depth, samples per pixel of a run = these two multiplied (the batch size is
+    # the renderer's own choice for the scene and image size)
     ("box_512_d5", "Box", 0, 512, 512, 5, 64, 4),
     ("box_1080p_d8", "Box", 0, 1920, 1080, 8, 32, 6),
     ("veggie_1080p_d8", "Veggie", 0, 1920, 1080, 8, 32, 6),
@@ -38,9 +39,12 @@ def run(name, scene_name, lattice, w, h, depth, spp, batches):
     if lattice:
         scene = scene.instance_lattice(10, lattice)
     cam = pt.Camera(resolution=(w, h))
+    r = pt.Renderer(scene, cam, max_depth=depth)
+    total = 2 * spp * batches
+    spp = r.stats()["iterations_per_batch"]
+    batches = max(2, total // spp)
     out = {"name": name, "scene": scene_name, "triangles": scene.n_triangles, "width": w, "height": h,
-           "depth": depth, "spp": spp * batches}
-    r = pt.Renderer(scene, cam, max_depth=depth, iterations_per_batch=spp)
+           "depth": depth, "spp": spp * batches, "batch_spp": spp}
     out["setup_s"] = time.perf_counter() - t0
     r.draw(2 * spp)  # one batch on each of the renderer's two streams
     r.synchronize()
