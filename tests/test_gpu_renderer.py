@@ -57,13 +57,15 @@ def test_two_streams_render_the_image_of_one(pt):
     assert np.array_equal(a, b) and np.all(a[..., 3] == 3)
 
 
-@pytest.mark.parametrize("name,lattice", [("Box", 0), ("Veggie", 0), ("Veggie", 3)])
+@pytest.mark.parametrize("name,lattice", [("Box", 0), ("Veggie", 0), ("Veggie", 3), ("Box_Transmission", 0),
+                                          ("Box_TransmissionSphere", 0)])
 def test_all_bounces_in_one_launch_render_what_separate_launches_render(pt, name, lattice):
     """A small batch runs all its bounces in one launch (a wave carries its regions of the queues through
     traversal and shading of every bounce); profile bit 4 asks for one launch per kernel and bounce
-    instead.  Same image, same counts -- for a scene that lives in LDS in small blocks (Box), in one
-    large block (Veggie) and one whose tree is read from memory (38 890 triangles) -- and the same again
-    as a batch too large for the one launch."""
+    instead.  Same image, same counts -- for a scene that lives in LDS in small blocks (Box), in two
+    512-thread blocks per CU (Box_Transmission), in one large block with all its triangles
+    (Box_TransmissionSphere) or with the hottest ones (Veggie), and one whose tree is read from memory
+    (38 890 triangles) -- and the same again as a batch too large for the one launch."""
     scene = pt.Scene.from_arrays(**scene_arrays(name))
     if lattice:
         scene = scene.instance_lattice(10, lattice)
@@ -79,7 +81,7 @@ def test_all_bounces_in_one_launch_render_what_separate_launches_render(pt, name
         assert st["segments"] == out[0][1]["segments"] and st["hits_shaded"] == out[0][1]["hits_shaded"]
     assert np.isfinite(out[0][0]).all() and np.all(out[0][0][..., 3] == 8)
     # 1080p: batches of 4 samples per pixel (8.3 M paths) go in one launch for every scene, batches of 32 only
-    # for a scene that lives in LDS in small blocks (Box); kernel by kernel they give the same image
+    # for a scene that lives in LDS with all its triangles; kernel by kernel they give the same image
     if not lattice:
         big = []
         for profile, calls in ((0, [4] * 8), (1, [32]), (17, [32])):
@@ -90,7 +92,7 @@ def test_all_bounces_in_one_launch_render_what_separate_launches_render(pt, name
             r.close()
         assert np.array_equal(big[0][0], big[1][0]) and np.array_equal(big[0][0], big[2][0])
         assert big[2][1]["launches_bounces"] == 0 and big[2][1]["launches_extend"] == 5
-        assert (big[1][1]["launches_bounces"] == 0) == (name != "Box")
+        assert (big[1][1]["launches_bounces"] == 0) == (name == "Veggie")
 
 
 def test_deterministic_across_runs(pt):
