@@ -9,6 +9,7 @@ reference rendered); no reference source is stored.
   python tests/golden/make_llvmpipe_fixtures.py timing   # llvmpipe throughput table
   python tests/golden/make_llvmpipe_fixtures.py ids_large  # hit buffers at benchmark sizes, a moved camera (minutes)
   python tests/golden/make_llvmpipe_fixtures.py post     # what post.frag draws from a float image
+  python tests/golden/make_llvmpipe_fixtures.py image_512  # Box at 512x512, depth 5, 64 spp
   python tests/golden/make_llvmpipe_fixtures.py image_filtered_4k  # Veggie at 3840x2160, kept as 16x16 block means (~25 min)
 """
 import glob
@@ -147,6 +148,9 @@ def main():
         # float images at the benchmark size and depth (iterations 0..15): Box ~1 min, Veggie ~6 min on 8 cores
         for n in sys.argv[2:] or ("Box", "Veggie"):
             image_fixture(n, 1920, 1080, 16, 8)
+    elif what == "image_512":
+        # the reference's own CPU-runnable configuration: Box, 512 x 512, depth 5, iterations 0..63 (~25 s)
+        image_fixture("Box", 512, 512, 64, 5)
     elif what == "image_filtered_4k":
         filtered_image_fixture("Veggie", 3840, 2160, 16, 8)
     elif what == "image_no_usemtl":

@@ -121,6 +121,37 @@ def test_veggie_at_3840x2160(pt):
     assert 0.02 < mean.min() and mean.max() < 0.15
 
 
+def test_box_512_depth5_image_against_reference(pt):
+    """The reference's own CPU-runnable configuration at its own size: Box.obj, 512x512, depth 5, iterations 0..63,
+    against the reference shader's float image of the same iterations (25 s of llvmpipe).  The gates of the 1080p
+    image test: per-pixel relMSE <= 2x the noise floor (two independent renders of our own) and <= a thousandth
+    of it (the same paths, not merely the same statistics), 16x16-filtered relMSE <= 2x its floor and
+    <= 3 x 2e-4 x 256/spp, channel means within 1 %."""
+    w, h, spp, depth = 512, 512, 64, 5
+    path = os.path.join(LLVMPIPE, f"image_Box_{w}x{h}_spp{spp}_depth{depth}.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    z = np.load(path)
+    ref = z["mean_rgb_f16"].astype(np.float32)
+    ref.ravel()[z["exact_index"]] = z["exact_value"]
+    ref = ref.astype(np.float64)
+    r = pt.Renderer(_scene(pt, "Box"), pt.Camera(resolution=(w, h)), max_depth=depth)
+    r.draw(spp)
+    s1 = r.read_sum()
+    r.draw(spp)
+    s2 = r.read_sum() - s1
+    r.close()
+    assert np.all(s1[..., 3] == spp)
+    a, b = s1[..., :3] / float(spp), s2[..., :3] / float(spp)
+    floor, floor_f = rel_mse(b, a), rel_mse(box_filter(b), box_filter(a))
+    got, got_f = rel_mse(a, ref), rel_mse(box_filter(a), box_filter(ref))
+    print(f"Box 512x512 depth 5, {spp} spp: per-pixel relMSE {got:.4g} (floor {floor:.4g}), filtered {got_f:.4g} (floor {floor_f:.4g})")
+    assert got <= 2.0 * floor + 1e-4 and got <= 1e-3 * floor, (got, floor)
+    assert got_f <= 2.0 * floor_f + 1e-5 and got_f <= 3.0 * 2.0e-4 * 256.0 / spp, (got_f, floor_f)
+    ma, mr = a.mean(axis=(0, 1)), ref.mean(axis=(0, 1))
+    assert np.all(np.abs(ma - mr) <= 0.01 * mr), (ma, mr)
+
+
 def test_veggie_image_against_reference_at_3840x2160(pt):
     """The image of the 4K configuration against the reference shader's at that size: Veggie, 3840x2160, depth 8,
     iterations 0..15 (llvmpipe takes 25 minutes for them on 8 cores).  A 4K float image does not fit in the
