@@ -45,6 +45,7 @@
 #define GL_FUNCS(X)                                        \
     X(PFNGLGETERRORPROC, glGetError)                       \
     X(PFNGLGETSTRINGPROC, glGetString)                     \
+    X(PFNGLGETINTEGERVPROC, glGetIntegerv)                 \
     X(PFNGLVIEWPORTPROC, glViewport)                       \
     X(PFNGLCREATESHADERPROC, glCreateShader)               \
     X(PFNGLSHADERSOURCEPROC, glShaderSource)               \
@@ -289,6 +290,13 @@ int main(int argc, char **argv)
     if (!name) die("missing GL entry point " #name);
     GL_FUNCS(LOAD)
     fprintf(stderr, "GL_RENDERER: %s\nGL_VERSION: %s\n", glGetString(GL_RENDERER), glGetString(GL_VERSION));
+    {
+        /* the scene arrays are buffer textures: a scene with more texels than this in one of them (6 per triangle in
+           the vertex-data texture) is not rendered as the shader means it -- fetches past the limit read zeros */
+        GLint max_texels = 0;
+        glGetIntegerv(GL_MAX_TEXTURE_BUFFER_SIZE, &max_texels);
+        fprintf(stderr, "GL_MAX_TEXTURE_BUFFER_SIZE: %d texels\n", max_texels);
+    }
 
     /* ---- the reference's shaders, patched in memory ---- */
     char path[4096];

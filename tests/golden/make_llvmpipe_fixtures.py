@@ -9,6 +9,7 @@ reference rendered); no reference source is stored.
   python tests/golden/make_llvmpipe_fixtures.py timing   # llvmpipe throughput table
   python tests/golden/make_llvmpipe_fixtures.py ids_large  # hit buffers at benchmark sizes, a moved camera (minutes)
   python tests/golden/make_llvmpipe_fixtures.py post     # what post.frag draws from a float image
+  python tests/golden/make_llvmpipe_fixtures.py image_lattice  # Veggie instanced 2^3 times (11 530 triangles), 256x256, depth 5
   python tests/golden/make_llvmpipe_fixtures.py image_512  # Box at 512x512, depth 5, 64 spp
   python tests/golden/make_llvmpipe_fixtures.py image_filtered_4k  # Veggie at 3840x2160, kept as 16x16 block means (~25 min)
 """
@@ -148,6 +149,28 @@ def main():
         # float images at the benchmark size and depth (iterations 0..15): Box ~1 min, Veggie ~6 min on 8 cores
         for n in sys.argv[2:] or ("Box", "Veggie"):
             image_fixture(n, 1920, 1080, 16, 8)
+    elif what == "image_lattice":
+        # Veggie's furniture instanced 2 x 2 x 2 times (11 530 triangles, pt_scene_instance_lattice): the kind of scene
+        # whose tree is read from memory, as large as llvmpipe can render -- its shader compiler ends every loop of
+        # an invocation once 65 535 iterations have been spent in all of them together (gallivm's guard against
+        # hangs), and the shader loops over all triangles for every segment: triangles x depth must stay below that
+        # (11 530 x 5 here; with 38 890 triangles the reference's image is black from the second segment on).
+        s = pt.Scene.load_npz(os.path.join(HERE, "scenes", "Veggie.npz")).instance_lattice(10, 2)
+        # (the default light hangs inside the lattice, where next to no camera path finds it: a second rectangle in
+        # the room's open front, facing in, lights the scene; the same two lights in the test)
+        s.set_lights([pt.make_light((4, 4, 4), (0, 1.95, 0), (3.14 / 2, 0, 0), (1.25, 1.25, 1)),
+                      pt.make_light((3, 3, 3), (0, 0.5, 2.5), (3.14159, 0, 0), (3, 3, 1))])
+        cam = pt.Camera(resolution=(256, 256))
+        cam.update()
+        t0 = time.time()
+        img, secs = rr.run(s.arrays(), (cam.eye, cam.forward, cam.up, cam.right), 256, 256, "float0", 16, 5)
+        rgb = img[..., :3].astype(np.float32)
+        half = rgb.astype(np.float16)
+        odd = np.flatnonzero(~(np.abs(half.astype(np.float32) - rgb) <= 1e-3 * np.abs(rgb)).ravel())
+        path = os.path.join(OUT, "image_Veggie_lattice2_256x256_spp16_depth5.npz")
+        np.savez_compressed(path, mean_rgb_f16=half, exact_index=odd.astype(np.int64), exact_value=rgb.ravel()[odd],
+                            spp=np.int32(16), depth=np.int32(5), llvmpipe_seconds=np.float64(secs))
+        print("lattice 2", rgb.mean(axis=(0, 1), dtype=np.float64), "%.1fs" % (time.time() - t0), os.path.getsize(path), flush=True)
     elif what == "image_512":
         # the reference's own CPU-runnable configuration: Box, 512 x 512, depth 5, iterations 0..63 (~25 s)
         image_fixture("Box", 512, 512, 64, 5)

@@ -152,6 +152,46 @@ def test_box_512_depth5_image_against_reference(pt):
     assert np.all(np.abs(ma - mr) <= 0.01 * mr), (ma, mr)
 
 
+def test_instanced_lattice_image_against_reference(pt):
+    """A scene of the traversal-stress kind, as large as the reference can render on llvmpipe: Veggie's furniture
+    instanced 2 x 2 x 2 times (11 530 triangles; the tree is read from memory), lit by a second rectangle in the
+    room's open front (the default light hangs inside the lattice), 256x256, depth 5, iterations 0..15, against
+    the reference shader's float image of the same scene arrays and iterations.  (llvmpipe ends all loops of a
+    shader invocation after 65 535 iterations in total, and the shader loops over all triangles per segment:
+    triangles x depth has to stay below that, which is what bounds this scene.)  Gates as for the other reference
+    images."""
+    w, h, spp, depth = 256, 256, 16, 5
+    path = os.path.join(LLVMPIPE, f"image_Veggie_lattice2_{w}x{h}_spp{spp}_depth{depth}.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    z = np.load(path)
+    ref = z["mean_rgb_f16"].astype(np.float32)
+    ref.ravel()[z["exact_index"]] = z["exact_value"]
+    ref = ref.astype(np.float64)
+    lat = _scene(pt, "Veggie").instance_lattice(10, 2)
+    lat.set_lights([pt.make_light((4, 4, 4), (0, 1.95, 0), (3.14 / 2, 0, 0), (1.25, 1.25, 1)),
+                    pt.make_light((3, 3, 3), (0, 0.5, 2.5), (3.14159, 0, 0), (3, 3, 1))])
+    assert lat.arrays()["indices"].shape[0] == 11_530
+    r = pt.Renderer(lat, pt.Camera(resolution=(w, h)), max_depth=depth)
+    r.draw(spp)
+    s1 = r.read_sum()
+    st = r.stats()
+    r.draw(spp)
+    s2 = r.read_sum() - s1
+    r.close()
+    assert np.all(s1[..., 3] == spp)
+    a, b = s1[..., :3] / float(spp), s2[..., :3] / float(spp)
+    floor, floor_f = rel_mse(b, a), rel_mse(box_filter(b), box_filter(a))
+    got, got_f = rel_mse(a, ref), rel_mse(box_filter(a), box_filter(ref))
+    print(f"lattice 2 ({st['n_nodes']} nodes), {spp} spp: per-pixel relMSE {got:.4g} (floor {floor:.4g}), filtered {got_f:.4g} "
+          f"(floor {floor_f:.4g}), mean {a.mean():.4g}")
+    assert ref.mean() > 0.05  # a lit scene
+    assert got <= 2.0 * floor + 1e-4 and got <= 1e-2 * floor, (got, floor)
+    assert got_f <= 2.0 * floor_f + 1e-5, (got_f, floor_f)
+    ma, mr = a.mean(axis=(0, 1)), ref.mean(axis=(0, 1))
+    assert np.all(np.abs(ma - mr) <= 0.01 * mr), (ma, mr)
+
+
 def test_veggie_image_against_reference_at_3840x2160(pt):
     """The image of the 4K configuration against the reference shader's at that size: Veggie, 3840x2160, depth 8,
     iterations 0..15 (llvmpipe takes 25 minutes for them on 8 cores).  A 4K float image does not fit in the
