@@ -9,6 +9,7 @@ reference rendered); no reference source is stored.
   python tests/golden/make_llvmpipe_fixtures.py timing   # llvmpipe throughput table
   python tests/golden/make_llvmpipe_fixtures.py ids_large  # hit buffers at benchmark sizes, a moved camera (minutes)
   python tests/golden/make_llvmpipe_fixtures.py post     # what post.frag draws from a float image
+  python tests/golden/make_llvmpipe_fixtures.py two_lights  # Box with two overlapping lights, both array orders
   python tests/golden/make_llvmpipe_fixtures.py image_lattice  # Veggie instanced 2^3 times (11 530 triangles), 256x256, depth 5
   python tests/golden/make_llvmpipe_fixtures.py image_512  # Box at 512x512, depth 5, 64 spp
   python tests/golden/make_llvmpipe_fixtures.py image_filtered_4k  # Veggie at 3840x2160, kept as 16x16 block means (~25 min)
@@ -149,6 +150,28 @@ def main():
         # float images at the benchmark size and depth (iterations 0..15): Box ~1 min, Veggie ~6 min on 8 cores
         for n in sys.argv[2:] or ("Box", "Veggie"):
             image_fixture(n, 1920, 1080, 16, 8)
+    elif what == "two_lights":
+        # Box with two rectangles that overlap on screen, in both orders of the light array: the shader's loop over
+        # lights (frag:418-430) sets t = 0 at the first light it accepts, after which no later light can win -- the
+        # first light of the ARRAY that the ray meets is the one reported, not the nearest.  Hit codes of both
+        # orders and a float image of one.
+        s = pt.Scene.load_npz(os.path.join(HERE, "scenes", "Box.npz"))
+        cam = pt.Camera(resolution=(256, 256))
+        cam.update()
+        c = (cam.eye, cam.forward, cam.up, cam.right)
+        a_light = pt.make_light((4, 4, 4), (0, 1.95, 0), (3.14 / 2, 0, 0), (1.25, 1.25, 1))
+        b_light = pt.make_light((1, 2, 3), (0.2, 1.93, 0.6), (3.14 / 2, 0, 0), (1.0, 1.0, 1))
+        out = {"lights_ab": np.stack([a_light, b_light]).astype(np.float32)}
+        for name, lights in (("ab", [a_light, b_light]), ("ba", [b_light, a_light])):
+            s.set_lights(lights)
+            img, _ = rr.run(s.arrays(), c, 256, 256, "ids", 1, 0)
+            out["ids_" + name] = img[..., 3].astype(np.int32)
+        img, secs = rr.run(s.arrays(), c, 256, 256, "float0", 16, 8)  # order b, a
+        out["mean_rgb_ba"] = img[..., :3].astype(np.float32)
+        path = os.path.join(OUT, "two_lights_Box_256x256.npz")
+        np.savez_compressed(path, spp=np.int32(16), depth=np.int32(8), **out)
+        print("two lights", {k: int((out["ids_ab"] == k).sum()) for k in (-2, -3)},
+              {k: int((out["ids_ba"] == k).sum()) for k in (-2, -3)}, out["mean_rgb_ba"].mean(axis=(0, 1)), os.path.getsize(path), flush=True)
     elif what == "image_lattice":
         # Veggie's furniture instanced 2 x 2 x 2 times (11 530 triangles, pt_scene_instance_lattice): the kind of scene
         # whose tree is read from memory, as large as llvmpipe can render -- its shader compiler ends every loop of

@@ -503,6 +503,35 @@ def test_two_lights_and_no_light_use_the_general_light_test(pt, ob):
             assert not sums[0][..., :3].any()
 
 
+def test_two_overlapping_lights_against_the_reference(pt):
+    """Two rectangles that overlap on screen, in both orders of the light array, against the reference's hit codes
+    (the first light of the array that a ray meets wins, frag:418-430: in 77 pixels the winner changes with the
+    order), and the image of one order against the reference shader's float image of the same iterations."""
+    path = os.path.join(LLVMPIPE, "two_lights_Box_256x256.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    z = np.load(path)
+    ab = z["lights_ab"]
+    for name, lights in (("ab", ab), ("ba", ab[::-1])):
+        a = _box_with_lights(pt, list(lights))
+        r = pt.Renderer(pt.Scene.from_arrays(**a), pt.Camera(resolution=(256, 256)), max_depth=8)
+        ids, _, _ = r.read_hit_ids(0)
+        assert np.array_equal(ids, z["ids_" + name]), name
+        if name == "ba":
+            spp = int(z["spp"])
+            r.draw(spp)
+            s1 = r.read_sum()
+            r.draw(spp)
+            s2 = r.read_sum() - s1
+            img, other, ref = s1[..., :3] / spp, s2[..., :3] / spp, z["mean_rgb_ba"].astype(np.float64)
+            floor, got = rel_mse(other, img), rel_mse(img, ref)
+            floor_f, got_f = rel_mse(box_filter(other), box_filter(img)), rel_mse(box_filter(img), box_filter(ref))
+            print(f"two lights: per-pixel relMSE {got:.4g} (floor {floor:.4g}), filtered {got_f:.4g} (floor {floor_f:.4g})")
+            assert got <= 1e-2 * floor and got_f <= 1e-2 * floor_f
+            assert np.all(np.abs(img.mean(axis=(0, 1)) - ref.mean(axis=(0, 1))) <= 0.01 * ref.mean(axis=(0, 1)))
+        r.close()
+
+
 def test_one_light_limit_equals_general_light_test(pt):
     """The same one-light scene rendered through the BVH kernel (light distance
     as the traversal limit) and through the scan kernel (light tested when the

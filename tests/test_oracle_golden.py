@@ -124,6 +124,24 @@ def test_light_inverse_reproduces_light_mask(ob):
     assert np.allclose(inv.reshape(4, 4).T.astype(np.float64) @ m, np.eye(4), atol=1e-6)
 
 
+def test_two_overlapping_lights_in_both_array_orders(ob):
+    """The shader's loop over lights (frag:418-430) sets t = 0 at the first light it accepts, so the light that a
+    ray is reported to hit is the first one of the ARRAY it meets, not the nearest.  Fixture: the reference's
+    hit codes for Box with two rectangles that overlap on screen, in both orders of the array (in 77 pixels the
+    winner changes with the order)."""
+    path = os.path.join(LLVMPIPE, "two_lights_Box_256x256.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    z = np.load(path)
+    ab = z["lights_ab"]
+    assert int(((z["ids_ab"] == -2) & (z["ids_ba"] == -2)).sum()) == 77
+    for name, lights in (("ab", ab), ("ba", ab[::-1])):
+        a = dict(scene_arrays("Box"))
+        a["lights"] = np.ascontiguousarray(lights, np.float32)
+        ids, _, _ = ob.primary(ob.OracleScene(a), _camera(ob, 256, 256), 0)
+        assert np.array_equal(ids, z["ids_" + name]), name
+
+
 @pytest.mark.parametrize("name,depth,spp", [("Box", 8, 24), ("Box", 5, 24), ("Box_Anisotropic", 8, 24),
                                             ("AnisotropicTest", 8, 24), ("Box_Transmission", 8, 12)])
 def test_image_statistics_against_reference(ob, name, depth, spp):
