@@ -9,6 +9,7 @@ reference rendered); no reference source is stored.
   python tests/golden/make_llvmpipe_fixtures.py timing   # llvmpipe throughput table
   python tests/golden/make_llvmpipe_fixtures.py ids_large  # hit buffers at benchmark sizes, a moved camera (minutes)
   python tests/golden/make_llvmpipe_fixtures.py post     # what post.frag draws from a float image
+  python tests/golden/make_llvmpipe_fixtures.py images_all  # 64-spp images of the assets without a 256-spp one
   python tests/golden/make_llvmpipe_fixtures.py two_lights  # Box with two overlapping lights, both array orders
   python tests/golden/make_llvmpipe_fixtures.py image_lattice  # Veggie instanced 2^3 times (11 530 triangles), 256x256, depth 5
   python tests/golden/make_llvmpipe_fixtures.py image_512  # Box at 512x512, depth 5, 64 spp
@@ -150,6 +151,12 @@ def main():
         # float images at the benchmark size and depth (iterations 0..15): Box ~1 min, Veggie ~6 min on 8 cores
         for n in sys.argv[2:] or ("Box", "Veggie"):
             image_fixture(n, 1920, 1080, 16, 8)
+    elif what == "images_all":
+        # every bundled asset that has no 256-spp image: 64 spp at 256 x 256, depth 8 (the metallic sweeps, IOR,
+        # smooth shading, the material test scenes ...; ~15 min on 8 cores)
+        have = {"Box", "Box_Anisotropic", "AnisotropicTest", "Box_Transmission", "Box_TransmissionSphere", "Veggie"}
+        for n in sys.argv[2:] or [n for n in names if n not in have]:
+            image_fixture(n, 256, 256, 64, 8)
     elif what == "two_lights":
         # Box with two rectangles that overlap on screen, in both orders of the light array: the shader's loop over
         # lights (frag:418-430) sets t = 0 at the first light it accepts, after which no later light can win -- the

@@ -409,6 +409,53 @@ def test_image_against_reference_at_1920x1080(pt, name):
     assert np.all(np.abs(ma - mr) <= 0.01 * mr), (ma, mr)
 
 
+@pytest.mark.parametrize("name", ["Box_IOR", "Box_Metallic", "Box_MetallicColor", "Box_SmoothSphere", "TEST", "cube",
+                                  "materialTest", "metal_rough_smooth", "shadowTest", "smoothCube", "sphere",
+                                  "transmissionBox"])
+def test_image_against_reference_on_the_other_assets(pt, name):
+    """The bundled assets that are no benchmark configuration -- the metallic sweeps (the stochastic choice
+    between the metal and the dielectric lobe, frag:846), index-of-refraction and smooth-shading scenes, the material
+    tests: 256x256, depth 8, iterations 0..63 against the reference shader's float image of the same iterations.
+    Same gates as at 1920x1080: per-pixel relMSE <= 2x the noise floor (two independent renders of our own) and
+    far below it (the same paths: <= a hundredth of the floor), 16x16-filtered relMSE <= 2x its floor, channel
+    means within 1 % (or, for a nearly black frame, within 1e-4 absolute).
+    Box_SmoothSphere is the exception to "the same paths": its blue metal sphere has roughness 0.005, alpha =
+    roughness^2 = 2.5e-5, where the shader's float arithmetic breaks down -- a visible-normal sample of a metal
+    should weigh at most 1, single samples here weigh up to 733 in the reference's image and 248 in ours -- and
+    what comes out depends on the platform's sin / cos / pow / reciprocal to the last bit (llvmpipe's polynomials
+    there, libm-accurate functions here).  4.7 % of its pixels hold a sample that differs (2.1 % when our
+    division and square root are correctly rounded instead of the hardware's 1 ulp).  Red and green, which the
+    sphere does not reflect, agree like in every other scene; the blue channel's distribution differs (the same
+    mean within the noise, 0.108 against 0.100 ... 0.127 over six sample sets of ours, but more of it in extreme
+    samples there: clipped at 10 per pixel the reference's blue mean is 4 % below ours, outside our own spread
+    of 1.5 %).  Gated for this scene: relMSE against the floors, red and green means within 1 %, blue within 8 %."""
+    w, h, spp, depth = 256, 256, 64, 8
+    ref = _reference_image(name, w, h, spp, depth)
+    r = _renderer(pt, name, w, h, max_depth=depth)
+    r.draw(spp)
+    s1 = r.read_sum()
+    r.draw(spp)
+    s2 = r.read_sum() - s1
+    r.close()
+    assert np.all(s1[..., 3] == spp)
+    a, b = s1[..., :3] / float(spp), s2[..., :3] / float(spp)
+    floor, floor_f = rel_mse(b, a), rel_mse(box_filter(b), box_filter(a))
+    got, got_f = rel_mse(a, ref), rel_mse(box_filter(a), box_filter(ref))
+    print(f"{name} 256x256 {spp} spp: per-pixel relMSE {got:.4g} (floor {floor:.4g}), 16x16-filtered {got_f:.4g} (floor {floor_f:.4g})")
+    assert got <= 2.0 * floor + 1e-4, (got, floor)
+    if name != "Box_SmoothSphere":
+        assert got <= 1e-2 * floor + 1e-9, (got, floor)
+    assert got_f <= 2.0 * floor_f + 1e-5, (got_f, floor_f)
+    close = (np.abs(a - ref) <= 1e-2 * np.abs(ref) + 1e-5).all(axis=2).mean()
+    print(f"   pixels within 1 % of the reference's: {close:.4f}")
+    assert close >= (0.94 if name == "Box_SmoothSphere" else 0.98), close
+    # (means with every pixel clipped at 10: a single pixel of the smooth sphere's frame holds up to 733 in the
+    # reference's image and 248 in ours -- a tenth of the channel's mean in one sample)
+    ma, mr = np.minimum(a, 10.0).mean(axis=(0, 1)), np.minimum(ref, 10.0).mean(axis=(0, 1))
+    tol = np.array([0.01, 0.01, 0.08 if name == "Box_SmoothSphere" else 0.01])
+    assert np.all(np.abs(ma - mr) <= tol * mr + 1e-4), (ma, mr)
+
+
 def test_faces_without_usemtl_scatter_what_the_reference_scatters(pt):
     """cube.obj has no usemtl: its faces carry material id 0xFFFFFFFF (scene.h:133) and the shader's material
     fetches (frag:105-126) go out of range.  On llvmpipe those fetches return zeros -- an all-zero material,
